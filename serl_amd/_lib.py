@@ -1,0 +1,98 @@
+"""ctypes loader for libserl_hip.so (the C ABI declared in include/serl_hip.h).
+
+The product path has no CPU fallback: if the HIP library is missing or an entry point
+fails, this module raises.  PyTorch is used only for device memory / streams.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libserl_hip.so")
+
+c_p = C.c_void_p
+c_i = C.c_int
+c_u = C.c_uint
+c_ll = C.c_longlong
+c_f = C.c_float
+PP = C.POINTER(C.c_void_p)
+
+# name -> argtypes (restype is int status unless listed in _RESTYPE)
+_SIGS = {
+    "serl_version": [],
+    "serl_device_arch": [c_i, C.c_char_p, c_i],
+    "serl_conv2d_fwd": [c_i, PP, PP, PP, PP, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
+    "serl_conv2d_dgrad": [c_i, PP, PP, PP, PP, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
+    "serl_conv2d_wgrad_workspace_bytes": [c_i] * 9,
+    "serl_conv2d_wgrad": [c_i, PP, PP, PP, PP, c_p, c_ll, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
+    "serl_gemm": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i,
+                  c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll,
+                  c_i, c_ll, c_i, c_i, c_i, c_i, c_p],
+    "serl_ln_act_fwd": [c_p, c_i, c_ll, c_i, c_p, c_p, c_p, c_ll, c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
+    "serl_ln_act_bwd": [c_p, c_i, c_p, c_p, c_ll, c_p, c_i, c_p, c_p, c_p, c_ll, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
+    "serl_colsum": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_ll, c_p],
+    "serl_rowdot": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
+    "serl_copy2d": [c_p, c_i, c_p, c_i, c_i, c_i, c_p],
+    "serl_fill": [c_p, c_f, c_ll, c_p],
+    "serl_tanh_gaussian_fwd": [c_p, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_u, c_u, c_i, c_i, c_i, c_p],
+    "serl_tanh_gaussian_bwd": [c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_p, c_f, c_p, c_p, c_i, c_i, c_i, c_p],
+    "serl_td_loss": [c_p, c_i, c_p, c_p, c_p, c_p, c_f, c_p, c_i, c_i, c_f, c_p, c_p, c_p, c_p],
+    "serl_actor_loss": [c_p, c_i, c_i, c_p, c_p, c_p, c_p],
+    "serl_adam_polyak": [c_p, c_p, c_p, c_p, c_p, c_ll, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p],
+    "serl_temperature_update": [c_p, c_p, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p, c_p],
+    "serl_sle_fwd": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
+    "serl_sle_bwd": [c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    "serl_gather_crop_frames": [c_p, c_ll, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
+    "serl_gather_crop_packed": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
+    "serl_gather_window": [c_p, c_ll, c_p, c_p, c_i, c_i, c_i, c_p],
+    "serl_crop_offsets": [c_u, c_u, c_i, c_i, c_i, c_i, c_p, c_p],
+}
+_RESTYPE = {"serl_conv2d_wgrad_workspace_bytes": c_ll}
+
+EXPORTS = tuple(_SIGS) + ("serl_last_error",)
+
+_lib = None
+
+
+class SerlHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (once). Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SerlHipError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C serl_amd/csrc`). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, args in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = _RESTYPE.get(name, c_i)
+    lib.serl_last_error.argtypes = []
+    lib.serl_last_error.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str = ""):
+    if status != 0:
+        msg = load().serl_last_error().decode()
+        if status == 1:
+            raise ValueError(f"{what}: {msg}")
+        raise SerlHipError(f"{what}: {msg}")
+
+
+def call(name: str, *args):
+    lib = load()
+    check(getattr(lib, name)(*args), name)
+
+
+def ptr_table(ptrs):
+    """Host array of device pointers for the grouped conv entry points."""
+    arr = (C.c_void_p * len(ptrs))(*[int(p) if p else None for p in ptrs])
+    return C.cast(arr, PP), arr

@@ -1,0 +1,112 @@
+// Batched / segmented dense GEMM on the exact-fp32 MFMA pipe: every matmul of the MLP trunk, the
+// critic ensemble (flax nn.vmap over a leading ensemble axis, serl/networks/ensemble.py:14-22) and
+// the policy head, forward and backward, is one call of serl_gemm with different strides.
+//
+//   C[z][m][n] (+)= sum_k A[z][m][k] * B[z][k][n]          z = blockIdx.z (ensemble member)
+//   A elem = a[z*a_zs + seg*a_ss + m*a_ms + r*a_ks],  B elem = b[z*b_zs + seg*b_ss + r*b_ks + n*b_ns]
+//   with k = seg*seglen + r  (segments let one GEMM reduce over (member, feature) pairs).
+#include "igemm.h"
+
+struct GemmArgs {
+  const float* a; const float* b; float* c; const float* bias;
+  int M, N, K, seglen;
+  long long a_zs, a_ss, a_ms, a_ks;
+  long long b_zs, b_ss, b_ks, b_ns;
+  long long c_zs, c_ss /*split stride*/, c_ms;
+  long long bias_zs;
+  int klen, relu, accumulate;
+  FastDiv d_seg;
+};
+
+template <bool AK_, bool BN_>
+struct GemmP {
+  static constexpr bool A_KCONTIG = AK_, B_NCONTIG = BN_;
+  GemmArgs g;
+  struct Ctx { const float* a; const float* b; float* c; const float* bias; };
+  struct ARow { long long off; bool ok; };
+  struct AK { long long off; bool ok; };
+  struct BCol { long long off; bool ok; };
+  struct BK_ { long long off; bool ok; };
+  struct ORow { long long off; };
+  __device__ bool init(Ctx& c, int z) const {
+    c.a = g.a + z * g.a_zs; c.b = g.b + z * g.b_zs; c.c = g.c + z * g.c_zs;
+    c.bias = g.bias ? g.bias + z * g.bias_zs : nullptr;
+    return true;
+  }
+  __device__ int M(const Ctx&) const { return g.M; }
+  __device__ int N(const Ctx&) const { return g.N; }
+  __device__ int K(const Ctx&) const { return g.K; }
+  __device__ int ksplit_len() const { return g.klen; }
+  __device__ void a_row(const Ctx&, int m, ARow& r) const { r.ok = m < g.M; r.off = r.ok ? m * g.a_ms : 0; }
+  __device__ void a_k(const Ctx&, int k, int kend, AK& a) const {
+    a.ok = k < kend;
+    const uint32_t kk = a.ok ? k : 0;
+    const uint32_t seg = fd_div(kk, g.d_seg), r = kk - seg * g.seglen;
+    a.off = seg * g.a_ss + r * g.a_ks;
+  }
+  __device__ float a_load(const Ctx& c, const ARow& r, const AK& a) const {
+    const bool ok = r.ok && a.ok;
+    const float v = c.a[ok ? r.off + a.off : 0];
+    return ok ? v : 0.f;
+  }
+  __device__ void b_col(const Ctx&, int n, BCol& b) const { b.ok = n < g.N; b.off = b.ok ? n * g.b_ns : 0; }
+  __device__ void b_k(const Ctx&, int k, int kend, BK_& b) const {
+    b.ok = k < kend;
+    const uint32_t kk = b.ok ? k : 0;
+    const uint32_t seg = fd_div(kk, g.d_seg), r = kk - seg * g.seglen;
+    b.off = seg * g.b_ss + r * g.b_ks;
+  }
+  __device__ float b_load(const Ctx& c, const BK_& k, const BCol& n) const {
+    const bool ok = k.ok && n.ok;
+    const float v = c.b[ok ? k.off + n.off : 0];
+    return ok ? v : 0.f;
+  }
+  __device__ void o_row(const Ctx&, int m, ORow& o) const { o.off = m * g.c_ms; }
+  __device__ void store(const Ctx& c, const ORow& o, int n, int split, float v) const {
+    float* dst = c.c + split * g.c_ss + o.off + n;
+    if (c.bias) v += c.bias[n];
+    if (g.accumulate) v += *dst;
+    if (g.relu) v = fmaxf(v, 0.f);
+    *dst = v;
+  }
+};
+
+typedef TileCfg<64, 64, 16, 2, 2> T64x64;
+typedef TileCfg<128, 128, 16, 2, 2> T128x128;
+
+// layout codes: a_kcontig = 1 when consecutive k of A are adjacent in memory (else consecutive m are),
+//               b_ncontig = 1 when consecutive n of B are adjacent (else consecutive k are).
+extern "C" int serl_gemm(const float* a, const float* b, float* c, const float* bias, int nbatch, int M, int N, int K,
+                         int seglen, long long a_zs, long long a_ss, long long a_ms, long long a_ks, long long b_zs,
+                         long long b_ss, long long b_ks, long long b_ns, long long c_zs, long long c_ms,
+                         long long bias_zs, int nsplit, long long c_split_stride, int relu, int accumulate,
+                         int a_kcontig, int b_ncontig, void* stream) {
+  SERL_CHECK_ARG(a && b && c, "gemm: null pointer");
+  SERL_CHECK_ARG(nbatch >= 1 && M >= 1 && N >= 1 && K >= 1 && nsplit >= 1, "gemm: bad sizes");
+  SERL_CHECK_ARG(seglen >= 1 && K % seglen == 0, "gemm: K must be a multiple of seglen");
+  SERL_CHECK_ARG(nsplit == 1 || (!bias && !relu && !accumulate), "gemm: split-K output is raw partial sums");
+  GemmArgs g;
+  g.a = a; g.b = b; g.c = c; g.bias = bias; g.M = M; g.N = N; g.K = K; g.seglen = seglen;
+  g.a_zs = a_zs; g.a_ss = a_ss; g.a_ms = a_ms; g.a_ks = a_ks;
+  g.b_zs = b_zs; g.b_ss = b_ss; g.b_ks = b_ks; g.b_ns = b_ns;
+  g.c_zs = c_zs; g.c_ss = c_split_stride; g.c_ms = c_ms; g.bias_zs = bias_zs;
+  g.relu = relu; g.accumulate = accumulate;
+  g.d_seg = make_fastdiv(seglen);
+  int klen = cdiv(cdiv(K, nsplit), 16) * 16;
+  g.klen = klen;
+  const int ns = cdiv(K, klen);
+  SERL_CHECK_ARG(ns == nsplit, "gemm: nsplit %d does not tile K=%d in multiples of 16 (got %d)", nsplit, K, ns);
+  hipStream_t st = (hipStream_t)stream;
+  const bool big = (M >= 512 && N >= 512);
+#define GO(AK, BN)                                                                                       \
+  {                                                                                                      \
+    GemmP<AK, BN> p; p.g = g;                                                                            \
+    return big ? igemm_launch<GemmP<AK, BN>, T128x128>(p, M, N, nsplit, nbatch, st, "gemm")              \
+               : igemm_launch<GemmP<AK, BN>, T64x64>(p, M, N, nsplit, nbatch, st, "gemm");               \
+  }
+  if (a_kcontig && b_ncontig) GO(true, true)
+  if (a_kcontig && !b_ncontig) GO(true, false)
+  if (!a_kcontig && b_ncontig) GO(false, true)
+  GO(false, false)
+#undef GO
+}

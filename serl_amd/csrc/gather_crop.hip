@@ -1,0 +1,171 @@
+// Frame-stack gather + DrQ random-shift ("pad by 4, crop back") augmentation, uint8, bit-exact.
+//
+// Replaces, in one pass over HBM, three reference steps:
+//   * sliding_window_view(frames, S+1)[indx - S]   serl/data/memory_efficient_replay_buffer.py:155-160
+//   * _unpack (obs = [..., :-1], next = [..., 1:])   serl/utils/commons.py:16-24
+//   * batched_random_crop(edge pad 4 + dynamic_slice) serl/utils/augmentations.py:5-11,44-48
+// Output layout = reference layout: (n, H, W, 3, S) uint8, i.e. channel index c*S + s after the
+// reshape of pixel_multiplexer.py:27.
+//
+// One block = one sample x {obs,next} x TH output rows.  Phase 1 stages the source rows in LDS with
+// 16-byte coalesced loads, phase 2 de-interleaves/shifts pixel by pixel inside LDS, phase 3 streams
+// the finished rows out with 16-byte coalesced stores.
+#include "common.h"
+
+#define GC_TH 8
+
+struct GcArgs {
+  const unsigned char* src;   // FRAMES: (cap, H, W, 3)   PACKED: (n, H, W, 3, S+1)
+  const long long* indx;      // FRAMES only: (n) replay indices (window = rows indx-S .. indx)
+  const int* off_obs;         // (n, 2) int32 (dy, dx) in [0, 2*pad]
+  const int* off_next;
+  unsigned char* out_obs;     // (n, H, W, 3*S)
+  unsigned char* out_next;
+  int n, H, W, S, pad, cap;
+};
+
+template <bool PACKED>
+__global__ __launch_bounds__(256) void gather_crop_kernel(const GcArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int j = blockIdx.x, which = blockIdx.y, y0 = blockIdx.z * GC_TH;
+  const int S = a.S, W = a.W, H = a.H;
+  const int rowb = W * 3;                      // bytes of one source frame row
+  const int srow = PACKED ? rowb * (S + 1) : rowb;  // bytes of one staged source row
+  const int nsrc = PACKED ? 1 : S;             // staged planes
+  unsigned char* s_src = smem;                                  // [nsrc][TH][srow]
+  unsigned char* s_out = smem + nsrc * GC_TH * srow;            // [TH][rowb*S]
+  const int* off = which ? a.off_next : a.off_obs;
+  const int dy = off[2 * j] - a.pad, dx = off[2 * j + 1] - a.pad;
+  const int rows = min(GC_TH, H - y0);
+
+  // ---- phase 1: global -> LDS, 16 B per lane
+  long long w0 = 0;
+  if (!PACKED) {
+    w0 = a.indx[j] - S;
+    if (w0 < 0) w0 += a.cap - S;  // python negative index into the (cap - S)-long window view
+  }
+  const int vec_per_row = srow / 16;
+  const int nvec = nsrc * rows * vec_per_row;
+  for (int v = threadIdx.x; v < nvec; v += 256) {
+    const int p = v / (rows * vec_per_row);
+    const int rem = v - p * rows * vec_per_row;
+    const int r = rem / vec_per_row, q = rem - r * vec_per_row;
+    int sy = y0 + r + dy;
+    sy = sy < 0 ? 0 : (sy >= H ? H - 1 : sy);
+    const unsigned char* g;
+    if (PACKED) g = a.src + ((long long)j * H + sy) * srow + q * 16;
+    else g = a.src + ((w0 + p + which) * H + sy) * (long long)rowb + q * 16;
+    *(uint4*)(s_src + (p * GC_TH + r) * srow + q * 16) = *(const uint4*)g;
+  }
+  __syncthreads();
+
+  // ---- phase 2: per output pixel, pull 3 bytes from each of the S frames, interleave as c*S + s
+  const int orow = rowb * S;
+  for (int px = threadIdx.x; px < rows * W; px += 256) {
+    const int r = px / W, x = px - r * W;
+    int sx = x + dx;
+    sx = sx < 0 ? 0 : (sx >= W ? W - 1 : sx);
+    unsigned char* o = s_out + r * orow + x * 3 * S;
+    for (int s = 0; s < S; ++s) {
+      const unsigned char* sp;
+      if (PACKED) sp = s_src + r * srow + sx * 3 * (S + 1) + (s + which);
+      else sp = s_src + (s * GC_TH + r) * srow + sx * 3;
+      const int cs = PACKED ? (S + 1) : 1;
+      o[0 * S + s] = sp[0];
+      o[1 * S + s] = sp[cs];
+      o[2 * S + s] = sp[2 * cs];
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 3: LDS -> global, 16 B per lane
+  unsigned char* out = (which ? a.out_next : a.out_obs) + ((long long)j * H + y0) * orow;
+  const int ovec = rows * orow / 16;
+  for (int v = threadIdx.x; v < ovec; v += 256) *(uint4*)(out + v * 16) = *(const uint4*)(s_out + v * 16);
+}
+
+static int gc_launch(const GcArgs& a, bool packed, hipStream_t st) {
+  const int rowb = a.W * 3;
+  SERL_CHECK_ARG(rowb % 16 == 0, "gather_crop: W*3 must be a multiple of 16 bytes");
+  SERL_CHECK_ARG((rowb * a.S * GC_TH) % 16 == 0, "gather_crop: output row tile not 16-byte sized");
+  SERL_CHECK_ARG(((uintptr_t)a.src & 15) == 0 && ((uintptr_t)a.out_obs & 15) == 0 && ((uintptr_t)a.out_next & 15) == 0,
+                 "gather_crop: buffers must be 16-byte aligned");
+  SERL_CHECK_ARG(a.H % GC_TH == 0, "gather_crop: H must be a multiple of %d", GC_TH);
+  const int srow = packed ? rowb * (a.S + 1) : rowb;
+  const int nsrc = packed ? 1 : a.S;
+  const size_t lds = (size_t)nsrc * GC_TH * srow + (size_t)GC_TH * rowb * a.S;
+  SERL_CHECK_ARG(lds <= 64 * 1024, "gather_crop: tile needs %zu B of LDS", lds);
+  dim3 grid(a.n, 2, a.H / GC_TH);
+  if (packed) hipLaunchKernelGGL(gather_crop_kernel<true>, grid, dim3(256), lds, st, a);
+  else hipLaunchKernelGGL(gather_crop_kernel<false>, grid, dim3(256), lds, st, a);
+  SERL_CHECK_LAUNCH("gather_crop");
+  return SERL_OK;
+}
+
+// frames: device-resident frame store (cap,H,W,3); indx: device int64 (n).
+extern "C" int serl_gather_crop_frames(const unsigned char* frames, long long cap, const long long* indx,
+                                       const int* off_obs, const int* off_next, unsigned char* out_obs,
+                                       unsigned char* out_next, int n, int H, int W, int S, int pad, void* stream) {
+  SERL_CHECK_ARG(frames && indx && off_obs && off_next && out_obs && out_next, "gather_crop_frames: null pointer");
+  SERL_CHECK_ARG(n >= 1 && S >= 1 && cap > S && cap < (1ll << 31), "gather_crop_frames: bad sizes");
+  GcArgs a{frames, indx, off_obs, off_next, out_obs, out_next, n, H, W, S, pad, (int)cap};
+  return gc_launch(a, false, (hipStream_t)stream);
+}
+
+// packed: (n,H,W,3,S+1) as returned by sample(pack_obs_and_next_obs=True).
+extern "C" int serl_gather_crop_packed(const unsigned char* packed, const int* off_obs, const int* off_next,
+                                       unsigned char* out_obs, unsigned char* out_next, int n, int H, int W, int S,
+                                       int pad, void* stream) {
+  SERL_CHECK_ARG(packed && off_obs && off_next && out_obs && out_next, "gather_crop_packed: null pointer");
+  SERL_CHECK_ARG(n >= 1 && S >= 1, "gather_crop_packed: bad sizes");
+  GcArgs a{packed, nullptr, off_obs, off_next, out_obs, out_next, n, H, W, S, pad, 0};
+  return gc_launch(a, true, (hipStream_t)stream);
+}
+
+// Plain window gather (no shift), used by the device-resident buffer's sample(): out (n,H,W,3,S+1).
+__global__ __launch_bounds__(256) void gather_window_kernel(const unsigned char* frames, int cap, const long long* indx,
+                                                            unsigned char* out, int HW3, int S) {
+  const int j = blockIdx.x;
+  long long w0 = indx[j] - S;
+  if (w0 < 0) w0 += cap - S;
+  const int T = S + 1;
+  for (int i = blockIdx.y * 256 + threadIdx.x; i < HW3; i += gridDim.y * 256) {
+    for (int t = 0; t < T; ++t) out[((long long)j * HW3 + i) * T + t] = frames[(w0 + t) * HW3 + i];
+  }
+}
+extern "C" int serl_gather_window(const unsigned char* frames, long long cap, const long long* indx, unsigned char* out,
+                                  int n, int HW3, int S, void* stream) {
+  SERL_CHECK_ARG(frames && indx && out && n >= 1 && HW3 >= 1 && S >= 1 && cap > S, "gather_window: bad args");
+  hipLaunchKernelGGL(gather_window_kernel, dim3(n, 16), dim3(256), 0, (hipStream_t)stream, frames, (int)cap, indx, out,
+                     HW3, S);
+  SERL_CHECK_LAUNCH("gather_window");
+  return SERL_OK;
+}
+
+// crop offsets: keys = split(key, n_total)[row]; (dy, dx) = randint(keys[row], (2,), 0, 2*pad+1)
+// (jax.random.randint: two splits, hi/lo 32-bit words, ((hi % span) * (2^32 % span) + lo % span) % span).
+__global__ void crop_offsets_kernel(uint32_t k0, uint32_t k1, int n, int row_offset, int n_total, int span, int* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t s0, s1;
+  threefry_split_child(k0, k1, (uint32_t)n_total, (uint32_t)(row_offset + i), s0, s1);
+  uint32_t a0, a1, b0, b1;
+  threefry_split_child(s0, s1, 2, 0, a0, a1);   // k1 of randint
+  threefry_split_child(s0, s1, 2, 1, b0, b1);   // k2
+  uint32_t h0 = 0, h1 = 1, l0 = 0, l1 = 1;      // random_bits(k, (2,)) = threefry(k, (0, 1))
+  threefry2x32(a0, a1, h0, h1);
+  threefry2x32(b0, b1, l0, l1);
+  const uint32_t sp = (uint32_t)span;
+  uint32_t mult = 65536u % sp;
+  mult = (mult * mult) % sp;
+  out[2 * i] = (int)(((h0 % sp) * mult + (l0 % sp)) % sp);
+  out[2 * i + 1] = (int)(((h1 % sp) * mult + (l1 % sp)) % sp);
+}
+extern "C" int serl_crop_offsets(unsigned k0, unsigned k1, int n, int row_offset, int n_total, int pad, int* out,
+                                 void* stream) {
+  SERL_CHECK_ARG(out && n >= 1 && pad >= 0 && row_offset >= 0 && row_offset + n <= n_total, "crop_offsets: bad args");
+  hipLaunchKernelGGL(crop_offsets_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, k0, k1, n, row_offset,
+                     n_total, 2 * pad + 1, out);
+  SERL_CHECK_LAUNCH("crop_offsets");
+  return SERL_OK;
+}

@@ -1,0 +1,515 @@
+// Row-wise and elementwise kernels of the SAC / RLPD update (HBM- or latency-bound; wave64
+// shuffles for the row statistics, float4 streams for the optimiser).
+#include "common.h"
+
+#define LN_EPS 1e-6f  // flax.linen.LayerNorm default (serl/networks/mlp.py:33)
+#define ACT_NONE 0
+#define ACT_RELU 1
+#define ACT_TANH 2
+#define MAXW 16  // row width <= 64*MAXW = 1024
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// ------------------------------------------------------------------ bias + LayerNorm + activation
+// z = sum_s pre[s] + bias ; y = act(LN(z)) (or act(z) when use_ln == 0).  One wave per row.
+// Rows are grouped (ensemble member e = row / rows_per_group) for bias / scale / shift.
+// flax 0.7 LayerNorm: var = max(0, E[z^2]-E[z]^2); y = (z-mean) * (rsqrt(var+eps)*scale) + shift.
+struct LnFwdArgs {
+  const float* pre; long long pre_ss; int nslab; int ldpre;
+  const float* bias; const float* gamma; const float* beta; long long pgs;  // per-group stride of params
+  float* y; int ldy; float* xhat; float* rstd;
+  int R, N, rows_per_group, use_ln, act;
+};
+__global__ __launch_bounds__(256) void ln_act_fwd_kernel(const LnFwdArgs a) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= a.R) return;
+  const int e = row / a.rows_per_group;
+  const float* bias = a.bias ? a.bias + e * a.pgs : nullptr;
+  float z[MAXW];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXW; ++i) {
+    const int n = lane + 64 * i;
+    float v = 0.f;
+    if (n < a.N) {
+      for (int s = 0; s < a.nslab; ++s) v += a.pre[s * a.pre_ss + (long long)row * a.ldpre + n];
+      if (bias) v += bias[n];
+    }
+    z[i] = v;
+    s1 += v;
+    s2 += v * v;
+  }
+  float mean = 0.f, mul = 1.f;
+  if (a.use_ln) {
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    mean = s1 / (float)a.N;
+    const float var = fmaxf(s2 / (float)a.N - mean * mean, 0.f);
+    mul = rsqrtf(var + LN_EPS);
+    if (a.rstd && lane == 0) a.rstd[row] = mul;
+  }
+  const float* gamma = a.use_ln ? a.gamma + e * a.pgs : nullptr;
+  const float* beta = a.use_ln ? a.beta + e * a.pgs : nullptr;
+#pragma unroll
+  for (int i = 0; i < MAXW; ++i) {
+    const int n = lane + 64 * i;
+    if (n < a.N) {
+      float v = z[i];
+      if (a.use_ln) {
+        const float xh = (v - mean) * mul;
+        if (a.xhat) a.xhat[(long long)row * a.N + n] = xh;
+        v = (v - mean) * (mul * gamma[n]) + beta[n];
+      }
+      if (a.act == ACT_RELU) v = fmaxf(v, 0.f);
+      else if (a.act == ACT_TANH) v = tanhf(v);
+      a.y[(long long)row * a.ldy + n] = v;
+    }
+  }
+}
+
+extern "C" int serl_ln_act_fwd(const float* pre, int nslab, long long pre_slab_stride, int ldpre, const float* bias,
+                               const float* gamma, const float* beta, long long param_group_stride, float* y, int ldy,
+                               float* xhat, float* rstd, int R, int N, int rows_per_group, int use_ln, int act,
+                               void* stream) {
+  SERL_CHECK_ARG(pre && y && R >= 1 && N >= 1 && N <= 64 * MAXW, "ln_act_fwd: bad args (N must be <= %d)", 64 * MAXW);
+  SERL_CHECK_ARG(!use_ln || (gamma && beta), "ln_act_fwd: LayerNorm needs scale and bias");
+  SERL_CHECK_ARG(rows_per_group >= 1 && nslab >= 1, "ln_act_fwd: bad grouping");
+  LnFwdArgs a{pre, pre_slab_stride, nslab, ldpre, bias, gamma, beta, param_group_stride, y, ldy, xhat, rstd,
+              R, N, rows_per_group, use_ln, act};
+  hipLaunchKernelGGL(ln_act_fwd_kernel, dim3(cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, a);
+  SERL_CHECK_LAUNCH("ln_act_fwd");
+  return SERL_OK;
+}
+
+// Backward of act(LN(z)): g = dy * act'(y); dxhat = g*gamma;
+// dz = rstd * (dxhat - mean(dxhat) - xhat*mean(dxhat*xhat)).  dy is either a dense (R,N) matrix with
+// row stride lddy, or the rank-1 form dq[row] * w[e][n] (gradient through a Dense(1) head).
+struct LnBwdArgs {
+  const float* dy; int lddy; const float* dq; const float* w_head; long long w_gs;
+  const float* y; int ldy; const float* xhat; const float* rstd; const float* gamma; long long pgs;
+  float* dz; float* g;
+  int R, N, rows_per_group, use_ln, act;
+};
+__global__ __launch_bounds__(256) void ln_act_bwd_kernel(const LnBwdArgs a) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= a.R) return;
+  const int e = row / a.rows_per_group;
+  const float* gamma = a.use_ln ? a.gamma + e * a.pgs : nullptr;
+  const float* wh = a.dq ? a.w_head + e * a.w_gs : nullptr;
+  const float dq = a.dq ? a.dq[row] : 0.f;
+  float gv[MAXW], xh[MAXW];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXW; ++i) {
+    const int n = lane + 64 * i;
+    float g = 0.f, x = 0.f;
+    if (n < a.N) {
+      const float d = a.dq ? dq * wh[n] : a.dy[(long long)row * a.lddy + n];
+      const float yv = a.y[(long long)row * a.ldy + n];
+      float dact = 1.f;
+      if (a.act == ACT_RELU) dact = yv > 0.f ? 1.f : 0.f;
+      else if (a.act == ACT_TANH) dact = 1.f - yv * yv;
+      g = d * dact;
+      if (a.use_ln) {
+        x = a.xhat[(long long)row * a.N + n];
+        const float dxh = g * gamma[n];
+        s1 += dxh;
+        s2 += dxh * x;
+      }
+    }
+    gv[i] = g;
+    xh[i] = x;
+  }
+  float m1 = 0.f, m2 = 0.f, rs = 1.f;
+  if (a.use_ln) {
+    m1 = wave_sum(s1) / (float)a.N;
+    m2 = wave_sum(s2) / (float)a.N;
+    rs = a.rstd[row];
+  }
+#pragma unroll
+  for (int i = 0; i < MAXW; ++i) {
+    const int n = lane + 64 * i;
+    if (n < a.N) {
+      float dz = gv[i];
+      if (a.use_ln) {
+        dz = rs * (gv[i] * gamma[n] - m1 - xh[i] * m2);
+        if (a.g) a.g[(long long)row * a.N + n] = gv[i];
+      }
+      a.dz[(long long)row * a.N + n] = dz;
+    }
+  }
+}
+
+extern "C" int serl_ln_act_bwd(const float* dy, int lddy, const float* dq, const float* w_head, long long w_group_stride,
+                               const float* y, int ldy, const float* xhat, const float* rstd, const float* gamma,
+                               long long param_group_stride, float* dz, float* g, int R, int N, int rows_per_group,
+                               int use_ln, int act, void* stream) {
+  SERL_CHECK_ARG((dy != nullptr) != (dq != nullptr), "ln_act_bwd: give exactly one of dy / dq");
+  SERL_CHECK_ARG(!dq || w_head, "ln_act_bwd: rank-1 form needs the head weights");
+  SERL_CHECK_ARG(y && dz && R >= 1 && N >= 1 && N <= 64 * MAXW, "ln_act_bwd: bad args");
+  SERL_CHECK_ARG(!use_ln || (xhat && rstd && gamma && g), "ln_act_bwd: LayerNorm needs xhat, rstd, scale, g");
+  LnBwdArgs a{dy, lddy, dq, w_head, w_group_stride, y, ldy, xhat, rstd, gamma, param_group_stride, dz, g,
+              R, N, rows_per_group, use_ln, act};
+  hipLaunchKernelGGL(ln_act_bwd_kernel, dim3(cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, a);
+  SERL_CHECK_LAUNCH("ln_act_bwd");
+  return SERL_OK;
+}
+
+// ------------------------------------------------------------------ column reductions over the batch
+// out_k[e][n] = sum_{r in group e} term_k[r][n], fixed summation order (reproducible):
+//   k=0: x0[r][n] * (w ? w[r] : 1) * (mul ? mul[r][n] : 1)      k=1: x1[r][n]      k=2: x2[r][n] * mul2[r][n]
+// Block = 32 columns x 8 row lanes; each row lane walks rows rl, rl+8, ...
+struct ColSumArgs {
+  const float* x0; const float* w; const float* mul; float* out0;
+  const float* x1; float* out1;
+  const float* x2; const float* mul2; float* out2;
+  int rows_per_group, N, ldx; long long out_gs;
+};
+__global__ __launch_bounds__(256) void colsum_kernel(const ColSumArgs a) {
+  __shared__ float red[3][8][33];
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int n = blockIdx.x * 32 + cl, e = blockIdx.y;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  if (n < a.N) {
+    for (int r = rl; r < a.rows_per_group; r += 8) {
+      const long long row = (long long)e * a.rows_per_group + r;
+      const long long i = row * a.ldx + n;
+      float v = a.x0[i];
+      if (a.w) v *= a.w[row];
+      if (a.mul) v *= a.mul[i];
+      s0 += v;
+      if (a.x1) s1 += a.x1[i];
+      if (a.x2) s2 += a.x2[i] * a.mul2[i];
+    }
+  }
+  red[0][rl][cl] = s0; red[1][rl][cl] = s1; red[2][rl][cl] = s2;
+  __syncthreads();
+  if (rl < 3 && n < a.N) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += red[rl][k][cl];
+    float* out = rl == 0 ? a.out0 : (rl == 1 ? a.out1 : a.out2);
+    if (out) out[e * a.out_gs + n] = s;
+  }
+}
+
+extern "C" int serl_colsum(const float* x0, const float* w, const float* mul, float* out0, const float* x1, float* out1,
+                           const float* x2, const float* mul2, float* out2, int ngroups, int rows_per_group, int N,
+                           int ldx, long long out_group_stride, void* stream) {
+  SERL_CHECK_ARG(x0 && out0 && ngroups >= 1 && rows_per_group >= 1 && N >= 1, "colsum: bad args");
+  SERL_CHECK_ARG((x1 != nullptr) == (out1 != nullptr), "colsum: x1/out1 mismatch");
+  SERL_CHECK_ARG((x2 != nullptr) == (out2 != nullptr) && (!x2 || mul2), "colsum: x2/mul2/out2 mismatch");
+  ColSumArgs a{x0, w, mul, out0, x1, out1, x2, mul2, out2, rows_per_group, N, ldx, out_group_stride};
+  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 32), ngroups), dim3(256), 0, (hipStream_t)stream, a);
+  SERL_CHECK_LAUNCH("colsum");
+  return SERL_OK;
+}
+
+// ------------------------------------------------------------------ Dense(1) head: q[r] = h[r,:].w[e,:] + b[e]
+__global__ __launch_bounds__(256) void rowdot_kernel(const float* h, const float* w, const float* b, float* q, int R,
+                                                     int N, int rows_per_group) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= R) return;
+  const int e = row / rows_per_group;
+  float s = 0.f;
+  for (int n = lane; n < N; n += 64) s += h[(long long)row * N + n] * w[(long long)e * N + n];
+  s = wave_sum(s);
+  if (lane == 0) q[row] = s + b[e];
+}
+extern "C" int serl_rowdot(const float* h, const float* w, const float* b, float* q, int R, int N, int rows_per_group,
+                           void* stream) {
+  SERL_CHECK_ARG(h && w && b && q && R >= 1 && N >= 1 && rows_per_group >= 1, "rowdot: bad args");
+  hipLaunchKernelGGL(rowdot_kernel, dim3(cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, h, w, b, q, R, N,
+                     rows_per_group);
+  SERL_CHECK_LAUNCH("rowdot");
+  return SERL_OK;
+}
+
+// ------------------------------------------------------------------ strided 2-D copy / fill (concat plumbing)
+__global__ void copy2d_kernel(float* dst, int ldd, const float* src, int lds, int rows, int cols) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)rows * cols) return;
+  const int r = (int)(i / cols), c = (int)(i - (long long)r * cols);
+  dst[(long long)r * ldd + c] = src[(long long)r * lds + c];
+}
+extern "C" int serl_copy2d(float* dst, int ldd, const float* src, int lds, int rows, int cols, void* stream) {
+  SERL_CHECK_ARG(dst && src && rows >= 1 && cols >= 1, "copy2d: bad args");
+  const long long n = (long long)rows * cols;
+  hipLaunchKernelGGL(copy2d_kernel, dim3((unsigned)cdivll(n, 256)), dim3(256), 0, (hipStream_t)stream, dst, ldd, src,
+                     lds, rows, cols);
+  SERL_CHECK_LAUNCH("copy2d");
+  return SERL_OK;
+}
+__global__ void fill_kernel(float* p, float v, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+extern "C" int serl_fill(float* p, float v, long long n, void* stream) {
+  SERL_CHECK_ARG(p && n >= 1, "fill: bad args");
+  hipLaunchKernelGGL(fill_kernel, dim3((unsigned)cdivll(n, 256)), dim3(256), 0, (hipStream_t)stream, p, v, n);
+  SERL_CHECK_LAUNCH("fill");
+  return SERL_OK;
+}
+
+// ------------------------------------------------------------------ tanh-Gaussian policy head
+// XLA's float32 erf_inv (Giles); jax.random.normal = sqrt(2) * erf_inv(uniform(nextafter(-1,0), 1)).
+__device__ __forceinline__ float erfinv_f32(float x) {
+  float w = -log1pf(-x * x);
+  float p;
+  if (w < 5.0f) {
+    w = w - 2.5f;
+    p = 2.81022636e-08f;
+    p = 3.43273939e-07f + p * w;
+    p = -3.5233877e-06f + p * w;
+    p = -4.39150654e-06f + p * w;
+    p = 0.00021858087f + p * w;
+    p = -0.00125372503f + p * w;
+    p = -0.00417768164f + p * w;
+    p = 0.246640727f + p * w;
+    p = 1.50140941f + p * w;
+  } else {
+    w = sqrtf(w) - 3.0f;
+    p = -0.000200214257f;
+    p = 0.000100950558f + p * w;
+    p = 0.00134934322f + p * w;
+    p = -0.00367342844f + p * w;
+    p = 0.00573950773f + p * w;
+    p = -0.0076224613f + p * w;
+    p = 0.00943887047f + p * w;
+    p = 1.00167406f + p * w;
+    p = 2.83297682f + p * w;
+  }
+  return fabsf(x) == 1.0f ? copysignf(INFINITY, x) : p * x;
+}
+__device__ __forceinline__ float jax_normal_from_bits(uint32_t bits) {
+  const float lo = -0.99999994f;  // nextafter(-1, 0)
+  const float u01 = __uint_as_float((bits >> 9) | 0x3F800000u) - 1.0f;
+  const float u = fmaxf(lo, u01 * (1.0f - lo) + lo);
+  return 1.41421356237309515f * erfinv_f32(u);
+}
+__device__ __forceinline__ float softplusf(float x) { return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x))); }
+
+// One thread per row.  mean / log_std_raw: (B, A) with row stride ld_ms (the two Dense heads write
+// side by side).  a = tanh(mean + exp(clip(log_std)) * eps); log pi(a) as TFP computes it from the
+// cached pre-tanh sample (serl/distributions/tanh_normal.py:41-48).  eps index = global row * A + j
+// of a (total_rows * A)-element jax.random.normal draw, so batch shards reproduce the global stream.
+struct TgArgs {
+  const float* mean; const float* lstd; int ld_ms;
+  float* act; int ld_act; float* xpre; float* eps; float* logp;
+  int B, A; uint32_t k0, k1; int row_offset, total_rows; int deterministic;
+};
+__global__ void tanh_gaussian_fwd_kernel(const TgArgs t) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= t.B) return;
+  float lp = 0.f;
+  for (int j = 0; j < t.A; ++j) {
+    const float mu = t.mean[(long long)b * t.ld_ms + j];
+    const float ls = fminf(fmaxf(t.lstd[(long long)b * t.ld_ms + j], -20.f), 2.f);
+    float e = 0.f;
+    if (!t.deterministic) {
+      const uint32_t idx = (uint32_t)(t.row_offset + b) * t.A + j;
+      e = jax_normal_from_bits(threefry_bits_at(t.k0, t.k1, idx, (uint32_t)t.total_rows * t.A));
+    }
+    const float x = mu + expf(ls) * e;
+    t.act[(long long)b * t.ld_act + j] = tanhf(x);
+    if (t.xpre) t.xpre[b * t.A + j] = x;
+    if (t.eps) t.eps[b * t.A + j] = e;
+    const float z = (x - mu) * expf(-ls);
+    lp += (-0.5f * z * z - ls - 0.918938533204672742f) - 2.f * (0.693147180559945309f - x - softplusf(-2.f * x));
+  }
+  if (t.logp) t.logp[b] = lp;
+}
+extern "C" int serl_tanh_gaussian_fwd(const float* mean, const float* log_std_raw, int ld_ms, float* act, int ld_act,
+                                      float* xpre, float* eps, float* logp, int B, int A, unsigned k0, unsigned k1,
+                                      int row_offset, int total_rows, int deterministic, void* stream) {
+  SERL_CHECK_ARG(mean && log_std_raw && act && B >= 1 && A >= 1, "tanh_gaussian_fwd: bad args");
+  SERL_CHECK_ARG(row_offset >= 0 && row_offset + B <= total_rows, "tanh_gaussian_fwd: shard outside the global batch");
+  TgArgs t{mean, log_std_raw, ld_ms, act, ld_act, xpre, eps, logp, B, A, k0, k1, row_offset, total_rows, deterministic};
+  hipLaunchKernelGGL(tanh_gaussian_fwd_kernel, dim3(cdiv(B, 64)), dim3(64), 0, (hipStream_t)stream, t);
+  SERL_CHECK_LAUNCH("tanh_gaussian_fwd");
+  return SERL_OK;
+}
+
+// Actor-loss backward through the head: L = mean_b(alpha*logp_b - q_b), da = dL/da from the critic path.
+//   dL/dmean = (alpha/Bg)*2a + da*(1-a^2);  dL/dlogstd = (alpha/Bg)*(-1 + 2a*sigma*eps) + da*(1-a^2)*sigma*eps,
+// zeroed where the raw log-std was clipped.  Output: dms (B, 2A) = [dmean | dlogstd] for the fused head GEMM.
+__global__ void tanh_gaussian_bwd_kernel(const float* act, int ld_act, const float* eps, const float* lstd, int ld_ms,
+                                         const float* da, int ld_da, const float* log_temp, float inv_batch,
+                                         float* dmean, float* dlstd, int ld_out, int B, int A) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * A) return;
+  const int b = i / A, j = i - b * A;
+  const float alpha = expf(log_temp[0]);
+  const float a = act[(long long)b * ld_act + j];
+  const float raw = lstd[(long long)b * ld_ms + j];
+  const float ls = fminf(fmaxf(raw, -20.f), 2.f);
+  const float se = expf(ls) * eps[i];
+  const float dla = da[(long long)b * ld_da + j] * (1.f - a * a);
+  const float c = alpha * inv_batch;
+  dmean[(long long)b * ld_out + j] = c * 2.f * a + dla;
+  const float dl = c * (-1.f + 2.f * a * se) + dla * se;
+  dlstd[(long long)b * ld_out + j] = (raw < -20.f || raw > 2.f) ? 0.f : dl;
+}
+extern "C" int serl_tanh_gaussian_bwd(const float* act, int ld_act, const float* eps, const float* log_std_raw,
+                                      int ld_ms, const float* da, int ld_da, const float* log_temp, float inv_batch,
+                                      float* dmean, float* dlstd, int ld_out, int B, int A, void* stream) {
+  SERL_CHECK_ARG(act && eps && log_std_raw && da && log_temp && dmean && dlstd, "tanh_gaussian_bwd: null pointer");
+  hipLaunchKernelGGL(tanh_gaussian_bwd_kernel, dim3(cdiv(B * A, 256)), dim3(256), 0, (hipStream_t)stream, act, ld_act,
+                     eps, log_std_raw, ld_ms, da, ld_da, log_temp, inv_batch, dmean, dlstd, ld_out, B, A);
+  SERL_CHECK_LAUNCH("tanh_gaussian_bwd");
+  return SERL_OK;
+}
+
+// ------------------------------------------------------------------ block reduction helper (<= 1024 threads)
+__device__ float block_sum(float v, float* sh) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[w] = v;
+  __syncthreads();
+  float s = 0.f;
+  for (int i = 0; i < nw; ++i) s += sh[i];
+  return s;
+}
+
+// ------------------------------------------------------------------ TD target + critic loss gradient
+// target = r + discount*mask*min_e next_q[e] (- discount*mask*alpha*next_logp if backup_entropy)
+// loss = mean_{e,b} (q - target)^2 ; dq = 2 (q - target) * inv_count  (sac_learner.py:185-209)
+// info_sums[0] += sum (q-t)^2, info_sums[1] += sum q  (divided on the host by the global E*B).
+__global__ __launch_bounds__(256) void td_loss_kernel(const float* next_q, int Emin, const float* rew, const float* mask,
+                                                      const float* next_logp, const float* log_temp, float discount,
+                                                      const float* q, int E, int B, float inv_count, float* target,
+                                                      float* dq, float* info) {
+  __shared__ float sh[4];
+  float l = 0.f, qs = 0.f;
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    float mn = next_q[b];
+    for (int e = 1; e < Emin; ++e) mn = fminf(mn, next_q[e * B + b]);
+    float t = rew[b] + discount * mask[b] * mn;
+    if (next_logp) t -= discount * mask[b] * expf(log_temp[0]) * next_logp[b];
+    target[b] = t;
+    for (int e = 0; e < E; ++e) {
+      const float qv = q[e * B + b], d = qv - t;
+      dq[e * B + b] = 2.f * d * inv_count;
+      l += d * d;
+      qs += qv;
+    }
+  }
+  l = block_sum(l, sh);
+  qs = block_sum(qs, sh);
+  if (threadIdx.x == 0) { info[0] = l; info[1] = qs; }
+}
+extern "C" int serl_td_loss(const float* next_q, int Emin, const float* rew, const float* mask, const float* next_logp,
+                            const float* log_temp, float discount, const float* q, int E, int B, float inv_count,
+                            float* target, float* dq, float* info, void* stream) {
+  SERL_CHECK_ARG(next_q && rew && mask && q && target && dq && info && Emin >= 1 && E >= 1 && B >= 1, "td_loss: bad args");
+  SERL_CHECK_ARG(!next_logp || log_temp, "td_loss: entropy backup needs log_temp");
+  hipLaunchKernelGGL(td_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, next_q, Emin, rew, mask, next_logp,
+                     log_temp, discount, q, E, B, inv_count, target, dq, info);
+  SERL_CHECK_LAUNCH("td_loss");
+  return SERL_OK;
+}
+
+// actor loss sums: info[0] = sum_b (alpha*logp_b - mean_e q[e,b]), info[1] = sum_b logp_b  (sac_learner.py:135-139)
+__global__ __launch_bounds__(256) void actor_loss_kernel(const float* q, int E, int B, const float* logp,
+                                                         const float* log_temp, float* info) {
+  __shared__ float sh[4];
+  const float alpha = expf(log_temp[0]);
+  float l = 0.f, lp = 0.f;
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    float qm = 0.f;
+    for (int e = 0; e < E; ++e) qm += q[e * B + b];
+    qm /= (float)E;
+    l += logp[b] * alpha - qm;
+    lp += logp[b];
+  }
+  l = block_sum(l, sh);
+  lp = block_sum(lp, sh);
+  if (threadIdx.x == 0) { info[0] = l; info[1] = lp; }
+}
+extern "C" int serl_actor_loss(const float* q, int E, int B, const float* logp, const float* log_temp, float* info,
+                               void* stream) {
+  SERL_CHECK_ARG(q && logp && log_temp && info && E >= 1 && B >= 1, "actor_loss: bad args");
+  hipLaunchKernelGGL(actor_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, q, E, B, logp, log_temp, info);
+  SERL_CHECK_LAUNCH("actor_loss");
+  return SERL_OK;
+}
+
+// ------------------------------------------------------------------ fused Adam (+ Polyak target) over a flat buffer
+// optax.adam: m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= lr * (m/bc1) / (sqrt(v/bc2) + eps)
+// optax.incremental_update: target = tau * p_new + (1 - tau) * target   (sac_learner.py:212-217)
+__global__ __launch_bounds__(256) void adam_polyak_kernel(float* __restrict__ p, float* __restrict__ m,
+                                                          float* __restrict__ v, const float* __restrict__ g,
+                                                          float* __restrict__ tgt, long long n, float lr, float b1,
+                                                          float b2, float eps, float bc1, float bc2, float tau,
+                                                          float gscale) {
+  const long long i4 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i4 >= n) return;
+  if (i4 + 4 <= n) {
+    float4 P = *(float4*)(p + i4), M = *(float4*)(m + i4), V = *(float4*)(v + i4);
+    const float4 G = *(const float4*)(g + i4);
+    float4 T;
+    if (tgt) T = *(float4*)(tgt + i4);
+    float* pp = (float*)&P; float* mm = (float*)&M; float* vv = (float*)&V; const float* gg = (const float*)&G;
+    float* tt = (float*)&T;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float gk = gg[k] * gscale;
+      mm[k] = b1 * mm[k] + (1.f - b1) * gk;
+      vv[k] = b2 * vv[k] + (1.f - b2) * gk * gk;
+      pp[k] = pp[k] - lr * ((mm[k] / bc1) / (sqrtf(vv[k] / bc2) + eps));
+      if (tgt) tt[k] = tau * pp[k] + (1.f - tau) * tt[k];
+    }
+    *(float4*)(p + i4) = P; *(float4*)(m + i4) = M; *(float4*)(v + i4) = V;
+    if (tgt) *(float4*)(tgt + i4) = T;
+  } else {
+    for (long long i = i4; i < n; ++i) {
+      const float gk = g[i] * gscale;
+      m[i] = b1 * m[i] + (1.f - b1) * gk;
+      v[i] = b2 * v[i] + (1.f - b2) * gk * gk;
+      p[i] = p[i] - lr * ((m[i] / bc1) / (sqrtf(v[i] / bc2) + eps));
+      if (tgt) tgt[i] = tau * p[i] + (1.f - tau) * tgt[i];
+    }
+  }
+}
+extern "C" int serl_adam_polyak(float* p, float* m, float* v, const float* g, float* target, long long n, float lr,
+                                float b1, float b2, float eps, float bc1, float bc2, float tau, float grad_scale,
+                                void* stream) {
+  SERL_CHECK_ARG(p && m && v && g && n >= 1, "adam_polyak: bad args");
+  SERL_CHECK_ARG((((uintptr_t)p | (uintptr_t)m | (uintptr_t)v | (uintptr_t)g | (uintptr_t)target) & 15) == 0,
+                 "adam_polyak: buffers must be 16-byte aligned");
+  const long long nthreads = cdivll(n, 4);
+  hipLaunchKernelGGL(adam_polyak_kernel, dim3((unsigned)cdivll(nthreads, 256)), dim3(256), 0, (hipStream_t)stream, p, m,
+                     v, g, target, n, lr, b1, b2, eps, bc1, bc2, tau, grad_scale);
+  SERL_CHECK_LAUNCH("adam_polyak");
+  return SERL_OK;
+}
+
+// Temperature: loss = alpha*(entropy - target_entropy); d/dlog_temp = same value; scalar Adam on device
+// (sac_learner.py:146-158).  entropy = -sum_logp * inv_batch is read from device memory (no host sync).
+// state = [log_temp, m, v]; info_out = [temperature, temperature_loss, entropy].
+__global__ void temperature_kernel(float* state, const float* sum_logp, float inv_batch, float target_entropy, float lr,
+                                   float b1, float b2, float eps, float bc1, float bc2, float* info_out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const float entropy = -sum_logp[0] * inv_batch;
+  const float temp = expf(state[0]);
+  const float g = temp * (entropy - target_entropy);
+  info_out[0] = temp; info_out[1] = g; info_out[2] = entropy;
+  const float m = b1 * state[1] + (1.f - b1) * g;
+  const float v = b2 * state[2] + (1.f - b2) * g * g;
+  state[0] = state[0] - lr * ((m / bc1) / (sqrtf(v / bc2) + eps));
+  state[1] = m; state[2] = v;
+}
+extern "C" int serl_temperature_update(float* state, const float* sum_logp, float inv_batch, float target_entropy,
+                                       float lr, float b1, float b2, float eps, float bc1, float bc2, float* info_out,
+                                       void* stream) {
+  SERL_CHECK_ARG(state && sum_logp && info_out, "temperature_update: null pointer");
+  hipLaunchKernelGGL(temperature_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, sum_logp, inv_batch,
+                     target_entropy, lr, b1, b2, eps, bc1, bc2, info_out);
+  SERL_CHECK_LAUNCH("temperature_update");
+  return SERL_OK;
+}

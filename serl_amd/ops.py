@@ -1,0 +1,132 @@
+"""Thin Python front of the C ABI: every function takes raw device pointers (ints, e.g.
+`tensor.data_ptr()`), sizes and a HIP stream handle, and enqueues hand-written HIP kernels.
+No computation happens in Python/torch here."""
+from __future__ import annotations
+
+from . import _lib
+from ._lib import call, ptr_table
+
+ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
+
+
+def current_stream() -> int:
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def conv2d_fwd(xs, ws, bs, ys, in_u8, B, IH, IW, C, KH, KW, stride, F, relu, stream):
+    n = len(xs)
+    px, kx = ptr_table(xs); pw, kw = ptr_table(ws); pb, kb = ptr_table(bs); py, ky = ptr_table(ys)
+    call("serl_conv2d_fwd", n, px, pw, pb, py, int(in_u8), B, IH, IW, C, KH, KW, stride, F, int(relu), stream)
+
+
+def conv2d_dgrad(dzs, ws, xacts, dxs, B, IH, IW, C, KH, KW, stride, F, stream):
+    n = len(dzs)
+    pz, kz = ptr_table(dzs); pw, kw = ptr_table(ws); pa, ka = ptr_table(xacts); pd, kd = ptr_table(dxs)
+    call("serl_conv2d_dgrad", n, pz, pw, pa, pd, B, IH, IW, C, KH, KW, stride, F, stream)
+
+
+def conv2d_wgrad_workspace_bytes(ngroups, B, IH, IW, C, KH, KW, stride, F) -> int:
+    r = _lib.load().serl_conv2d_wgrad_workspace_bytes(ngroups, B, IH, IW, C, KH, KW, stride, F)
+    if r < 0:
+        raise ValueError("conv2d_wgrad_workspace_bytes: " + _lib.load().serl_last_error().decode())
+    return int(r)
+
+
+def conv2d_wgrad(xs, dzs, dws, dbs, workspace, workspace_bytes, in_u8, B, IH, IW, C, KH, KW, stride, F, stream):
+    n = len(xs)
+    px, kx = ptr_table(xs); pz, kz = ptr_table(dzs); pw, kw = ptr_table(dws); pb, kb = ptr_table(dbs)
+    call("serl_conv2d_wgrad", n, px, pz, pw, pb, workspace, workspace_bytes, int(in_u8), B, IH, IW, C, KH, KW,
+         stride, F, stream)
+
+
+def gemm(a, b, c, bias, nbatch, M, N, K, *, a_zs=0, a_ms, a_ks, b_zs=0, b_ks, b_ns, c_zs=0, c_ms,
+         bias_zs=0, seglen=None, a_ss=0, b_ss=0, nsplit=1, c_split_stride=0, relu=False, accumulate=False,
+         a_kcontig=True, b_ncontig=True, stream=0):
+    call("serl_gemm", a, b, c, bias, nbatch, M, N, K, K if seglen is None else seglen,
+         a_zs, a_ss, a_ms, a_ks, b_zs, b_ss, b_ks, b_ns, c_zs, c_ms, bias_zs,
+         nsplit, c_split_stride, int(relu), int(accumulate), int(a_kcontig), int(b_ncontig), stream)
+
+
+def ln_act_fwd(pre, nslab, pre_ss, ldpre, bias, gamma, beta, pgs, y, ldy, xhat, rstd, R, N, rows_per_group,
+               use_ln, act, stream):
+    call("serl_ln_act_fwd", pre, nslab, pre_ss, ldpre, bias, gamma, beta, pgs, y, ldy, xhat, rstd, R, N,
+         rows_per_group, int(use_ln), act, stream)
+
+
+def ln_act_bwd(dy, lddy, dq, w_head, w_gs, y, ldy, xhat, rstd, gamma, pgs, dz, g, R, N, rows_per_group,
+               use_ln, act, stream):
+    call("serl_ln_act_bwd", dy, lddy, dq, w_head, w_gs, y, ldy, xhat, rstd, gamma, pgs, dz, g, R, N,
+         rows_per_group, int(use_ln), act, stream)
+
+
+def colsum(x0, out0, ngroups, rows_per_group, N, ldx, out_gs, stream, w=None, mul=None, x1=None, out1=None,
+           x2=None, mul2=None, out2=None):
+    call("serl_colsum", x0, w, mul, out0, x1, out1, x2, mul2, out2, ngroups, rows_per_group, N, ldx, out_gs, stream)
+
+
+def rowdot(h, w, b, q, R, N, rows_per_group, stream):
+    call("serl_rowdot", h, w, b, q, R, N, rows_per_group, stream)
+
+
+def copy2d(dst, ldd, src, lds, rows, cols, stream):
+    call("serl_copy2d", dst, ldd, src, lds, rows, cols, stream)
+
+
+def fill(p, v, n, stream):
+    call("serl_fill", p, float(v), n, stream)
+
+
+def tanh_gaussian_fwd(mean, lstd, ld_ms, act, ld_act, xpre, eps, logp, B, A, key, row_offset, total_rows,
+                      deterministic, stream):
+    call("serl_tanh_gaussian_fwd", mean, lstd, ld_ms, act, ld_act, xpre, eps, logp, B, A, int(key[0]), int(key[1]),
+         row_offset, total_rows, int(deterministic), stream)
+
+
+def tanh_gaussian_bwd(act, ld_act, eps, lstd, ld_ms, da, ld_da, log_temp, inv_batch, dmean, dlstd, ld_out, B, A,
+                      stream):
+    call("serl_tanh_gaussian_bwd", act, ld_act, eps, lstd, ld_ms, da, ld_da, log_temp, float(inv_batch), dmean,
+         dlstd, ld_out, B, A, stream)
+
+
+def td_loss(next_q, emin, rew, mask, next_logp, log_temp, discount, q, E, B, inv_count, target, dq, info, stream):
+    call("serl_td_loss", next_q, emin, rew, mask, next_logp, log_temp, float(discount), q, E, B, float(inv_count),
+         target, dq, info, stream)
+
+
+def actor_loss(q, E, B, logp, log_temp, info, stream):
+    call("serl_actor_loss", q, E, B, logp, log_temp, info, stream)
+
+
+def adam_polyak(p, m, v, g, target, n, lr, b1, b2, eps, bc1, bc2, tau, grad_scale, stream):
+    call("serl_adam_polyak", p, m, v, g, target, n, float(lr), float(b1), float(b2), float(eps), float(bc1),
+         float(bc2), float(tau), float(grad_scale), stream)
+
+
+def temperature_update(state, sum_logp, inv_batch, target_entropy, lr, b1, b2, eps, bc1, bc2, info_out, stream):
+    call("serl_temperature_update", state, sum_logp, float(inv_batch), float(target_entropy), float(lr), float(b1),
+         float(b2), float(eps), float(bc1), float(bc2), info_out, stream)
+
+
+def sle_fwd(feat, ker, out, ldo, B, HW, C, F, stream):
+    call("serl_sle_fwd", feat, ker, out, ldo, B, HW, C, F, stream)
+
+
+def sle_bwd(dout, ldo, ker, feat, dfeat, dker, B, HW, C, F, stream):
+    call("serl_sle_bwd", dout, ldo, ker, feat, dfeat, dker, B, HW, C, F, stream)
+
+
+def gather_crop_frames(frames, cap, indx, off_obs, off_next, out_obs, out_next, n, H, W, S, pad, stream):
+    call("serl_gather_crop_frames", frames, cap, indx, off_obs, off_next, out_obs, out_next, n, H, W, S, pad, stream)
+
+
+def gather_crop_packed(packed, off_obs, off_next, out_obs, out_next, n, H, W, S, pad, stream):
+    call("serl_gather_crop_packed", packed, off_obs, off_next, out_obs, out_next, n, H, W, S, pad, stream)
+
+
+def gather_window(frames, cap, indx, out, n, HW3, S, stream):
+    call("serl_gather_window", frames, cap, indx, out, n, HW3, S, stream)
+
+
+def crop_offsets(key, n, row_offset, n_total, pad, out, stream):
+    call("serl_crop_offsets", int(key[0]), int(key[1]), n, row_offset, n_total, pad, out, stream)

@@ -1,0 +1,447 @@
+"""GPU parity tests of every HIP kernel, called through the C ABI, against the CPU oracle
+(oracle/learner.py, oracle/prng.py) or a float64 numpy/torch statement of the same op.
+
+Tolerances: integer / byte work bit-exact; fp32 kernels rel 2e-5 of the output scale
+(the fp32 MFMA is an exact fmaf chain; differences are summation order only)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    from serl_amd import ops
+    return ops
+
+
+def close(got, ref, rtol=2e-5, what=""):
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    scale = max(1e-30, float(np.abs(ref).max()))
+    err = float(np.abs(got - ref).max()) / scale
+    assert err <= rtol, f"{what}: max err {err:.3e} of scale {scale:.3e}"
+
+
+def dv(a, dev, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(dev)
+
+
+# ---------------------------------------------------------------------------------- igemm: conv
+CONV_CASES = [
+    # B, IH, IW, C, K, S, F, u8
+    (3, 128, 128, 9, 3, 2, 32, True),     # E1 conv1 (uint8 input, K=81)
+    (2, 63, 63, 32, 3, 2, 64, False),     # E1 conv2
+    (2, 31, 31, 64, 3, 2, 128, False),    # E1 conv3
+    (5, 15, 15, 128, 3, 2, 256, False),   # E1 conv4
+    (2, 21, 19, 32, 3, 1, 32, False),     # E0-style stride 1, non-square
+    (1, 9, 9, 3, 2, 1, 5, False),         # odd sizes, filter 2
+]
+
+
+def _conv_ref(x, w, b, stride):
+    xt = torch.tensor(x, dtype=torch.float64).permute(0, 3, 1, 2)
+    wt = torch.tensor(w, dtype=torch.float64).permute(3, 2, 0, 1)
+    y = torch.nn.functional.conv2d(xt, wt, torch.tensor(b, dtype=torch.float64), stride=stride)
+    return y.permute(0, 2, 3, 1)
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(dev, case):
+    ops = _ops()
+    B, IH, IW, Cin, K, S, F, u8 = case
+    rng = np.random.default_rng(1)
+    G = 2
+    st = ops.current_stream()
+    xs, ws, bs, ys, refs = [], [], [], [], []
+    for g in range(G):
+        if u8:
+            x = rng.integers(0, 256, size=(B, IH, IW, Cin), dtype=np.uint8)
+            xf = (x.astype(np.float32) / np.float32(255.0))
+        else:
+            x = np.maximum(rng.standard_normal((B, IH, IW, Cin)).astype(np.float32), 0)
+            xf = x
+        w = (rng.standard_normal((K, K, Cin, F)) * 0.1).astype(np.float32)
+        b = (rng.standard_normal(F) * 0.1).astype(np.float32)
+        xs.append(dv(x, dev)); ws.append(dv(w, dev)); bs.append(dv(b, dev))
+        OH, OW = (IH - K) // S + 1, (IW - K) // S + 1
+        ys.append(torch.full((B, OH, OW, F), float("nan"), device=dev))
+        refs.append((xf, w, b))
+    ops.conv2d_fwd([t.data_ptr() for t in xs], [t.data_ptr() for t in ws], [t.data_ptr() for t in bs],
+                   [t.data_ptr() for t in ys], u8, B, IH, IW, Cin, K, K, S, F, True, st)
+    torch.cuda.synchronize()
+    dzs, dxs, dws, dbs = [], [], [], []
+    for g in range(G):
+        xf, w, b = refs[g]
+        yref = torch.relu(_conv_ref(xf, w, b, S))
+        close(ys[g].cpu().numpy(), yref.numpy(), what=f"conv fwd g{g}")
+        dz = rng.standard_normal((B, OH, OW, F)).astype(np.float32)
+        dz *= (yref.numpy() > 0)                      # already ReLU-masked, as the chain delivers it
+        dzs.append(dv(dz, dev))
+        dxs.append(torch.full((B, IH, IW, Cin), float("nan"), device=dev))
+        dws.append(torch.full((K, K, Cin, F), float("nan"), device=dev))
+        dbs.append(torch.full((F,), float("nan"), device=dev))
+    # --- wgrad (+ bias grad)
+    wsb = ops.conv2d_wgrad_workspace_bytes(G, B, IH, IW, Cin, K, K, S, F)
+    wsp = torch.empty(wsb // 4, device=dev)
+    ops.conv2d_wgrad([t.data_ptr() for t in xs], [t.data_ptr() for t in dzs], [t.data_ptr() for t in dws],
+                     [t.data_ptr() for t in dbs], wsp.data_ptr(), wsb, u8, B, IH, IW, Cin, K, K, S, F, st)
+    # --- dgrad with the ReLU mask of this layer's input
+    if not u8:
+        ops.conv2d_dgrad([t.data_ptr() for t in dzs], [t.data_ptr() for t in ws], [t.data_ptr() for t in xs],
+                         [t.data_ptr() for t in dxs], B, IH, IW, Cin, K, K, S, F, st)
+    torch.cuda.synchronize()
+    for g in range(G):
+        xf, w, b = refs[g]
+        xt = torch.tensor(xf, dtype=torch.float64, requires_grad=True)
+        wt = torch.tensor(w, dtype=torch.float64, requires_grad=True)
+        bt = torch.tensor(b, dtype=torch.float64, requires_grad=True)
+        y = torch.nn.functional.conv2d(xt.permute(0, 3, 1, 2), wt.permute(3, 2, 0, 1), bt, stride=S).permute(0, 2, 3, 1)
+        (y * torch.tensor(dzs[g].cpu().numpy(), dtype=torch.float64)).sum().backward()
+        close(dws[g].cpu().numpy(), wt.grad.numpy(), what=f"conv wgrad g{g}")
+        close(dbs[g].cpu().numpy(), bt.grad.numpy(), what=f"conv bias grad g{g}")
+        if not u8:
+            ref_dx = xt.grad.numpy() * (xf > 0)
+            close(dxs[g].cpu().numpy(), ref_dx, what=f"conv dgrad g{g}")
+
+
+# ---------------------------------------------------------------------------------- igemm: dense
+def test_gemm_variants(dev):
+    ops = _ops()
+    rng = np.random.default_rng(2)
+    st = ops.current_stream()
+    E, B, K, N = 3, 70, 83, 45
+    x = rng.standard_normal((B, K)).astype(np.float32)
+    w = rng.standard_normal((E, K, N)).astype(np.float32)
+    b = rng.standard_normal((E, N)).astype(np.float32)
+    X, W, Bi = dv(x, dev), dv(w, dev), dv(b, dev)
+    Y = torch.full((E, B, N), float("nan"), device=dev)
+    # fwd, shared input, ensemble weights, bias + relu
+    ops.gemm(X.data_ptr(), W.data_ptr(), Y.data_ptr(), Bi.data_ptr(), E, B, N, K, a_zs=0, a_ms=K, a_ks=1,
+             b_zs=K * N, b_ks=N, b_ns=1, c_zs=B * N, c_ms=N, bias_zs=N, relu=True, stream=st)
+    ref = np.maximum(np.einsum("bk,ekn->ebn", x.astype(np.float64), w.astype(np.float64)) + b[:, None, :], 0)
+    torch.cuda.synchronize()
+    close(Y.cpu().numpy(), ref, what="gemm fwd")
+    # dX = sum_e dY[e] @ W[e]^T  (segmented K over (e, n)); A k-contig, B k-contig
+    dy = rng.standard_normal((E, B, N)).astype(np.float32)
+    DY = dv(dy, dev)
+    DX = torch.full((B, K), float("nan"), device=dev)
+    ops.gemm(DY.data_ptr(), W.data_ptr(), DX.data_ptr(), None, 1, B, K, E * N, seglen=N, a_ss=B * N, a_ms=N, a_ks=1,
+             b_ss=K * N, b_ks=1, b_ns=N, c_ms=K, a_kcontig=True, b_ncontig=False, stream=st)
+    torch.cuda.synchronize()
+    close(DX.cpu().numpy(), np.einsum("ebn,ekn->bk", dy.astype(np.float64), w.astype(np.float64)), what="gemm dX")
+    # dW[e] = X^T @ dY[e]; A m-contig
+    DW = torch.full((E, K, N), float("nan"), device=dev)
+    ops.gemm(X.data_ptr(), DY.data_ptr(), DW.data_ptr(), None, E, K, N, B, a_zs=0, a_ms=1, a_ks=K,
+             b_zs=B * N, b_ks=N, b_ns=1, c_zs=K * N, c_ms=N, a_kcontig=False, b_ncontig=True, stream=st)
+    torch.cuda.synchronize()
+    close(DW.cpu().numpy(), np.einsum("bk,ebn->ekn", x.astype(np.float64), dy.astype(np.float64)), what="gemm dW")
+    # split-K slabs
+    nsplit = 3
+    SL = torch.full((nsplit, B, N), float("nan"), device=dev)
+    ops.gemm(X.data_ptr(), W.data_ptr(), SL.data_ptr(), None, 1, B, N, K, a_ms=K, a_ks=1, b_ks=N, b_ns=1, c_ms=N,
+             nsplit=nsplit, c_split_stride=B * N, stream=st)
+    torch.cuda.synchronize()
+    close(SL.cpu().numpy().sum(0), x.astype(np.float64) @ w[0].astype(np.float64), what="gemm split-K")
+    # big-tile path (M, N >= 512) with accumulate
+    M2, N2, K2 = 520, 530, 40
+    a2 = rng.standard_normal((M2, K2)).astype(np.float32); b2 = rng.standard_normal((K2, N2)).astype(np.float32)
+    c0 = rng.standard_normal((M2, N2)).astype(np.float32)
+    A2, B2, C2 = dv(a2, dev), dv(b2, dev), dv(c0, dev)
+    ops.gemm(A2.data_ptr(), B2.data_ptr(), C2.data_ptr(), None, 1, M2, N2, K2, a_ms=K2, a_ks=1, b_ks=N2, b_ns=1,
+             c_ms=N2, accumulate=True, stream=st)
+    torch.cuda.synchronize()
+    close(C2.cpu().numpy(), c0 + a2.astype(np.float64) @ b2.astype(np.float64), what="gemm 128 tile")
+
+
+# ---------------------------------------------------------------------------------- LN + activation
+@pytest.mark.parametrize("use_ln,act,N", [(True, 1, 256), (True, 2, 512), (True, 2, 64), (False, 1, 256), (True, 1, 50)])
+def test_ln_act_fwd_bwd(dev, use_ln, act, N):
+    ops = _ops()
+    rng = np.random.default_rng(3)
+    st = ops.current_stream()
+    E, B, nslab = 3, 37, 2
+    R = E * B
+    pre = rng.standard_normal((nslab, R, N)).astype(np.float32)
+    bias = rng.standard_normal((E, N)).astype(np.float32)
+    gam = (1 + 0.1 * rng.standard_normal((E, N))).astype(np.float32)
+    bet = (0.1 * rng.standard_normal((E, N))).astype(np.float32)
+    P, Bi, Ga, Be = dv(pre, dev), dv(bias, dev), dv(gam, dev), dv(bet, dev)
+    ldy = N + 7
+    Y = torch.zeros((R, ldy), device=dev)
+    XH = torch.zeros((R, N), device=dev); RS = torch.zeros((R,), device=dev)
+    ops.ln_act_fwd(P.data_ptr(), nslab, R * N, N, Bi.data_ptr(), Ga.data_ptr() if use_ln else None,
+                   Be.data_ptr() if use_ln else None, N, Y.data_ptr(), ldy, XH.data_ptr() if use_ln else None,
+                   RS.data_ptr() if use_ln else None, R, N, B, use_ln, act, st)
+    zt = torch.tensor(pre.astype(np.float64).sum(0).reshape(E, B, N) + bias[:, None, :], requires_grad=True)
+    h = zt
+    if use_ln:
+        mean = h.mean(-1, keepdim=True)
+        var = (h * h).mean(-1, keepdim=True) - mean * mean
+        h = (h - mean) * torch.rsqrt(var + 1e-6) * torch.tensor(gam, dtype=torch.float64)[:, None, :] \
+            + torch.tensor(bet, dtype=torch.float64)[:, None, :]
+    yref = torch.relu(h) if act == 1 else torch.tanh(h)
+    torch.cuda.synchronize()
+    close(Y.cpu().numpy()[:, :N], yref.detach().numpy().reshape(R, N), what="ln fwd")
+    dy = rng.standard_normal((R, N)).astype(np.float32)
+    DY = dv(dy, dev)
+    DZ = torch.zeros((R, N), device=dev); G = torch.zeros((R, N), device=dev)
+    ops.ln_act_bwd(DY.data_ptr(), N, None, None, 0, Y.data_ptr(), ldy, XH.data_ptr() if use_ln else None,
+                   RS.data_ptr() if use_ln else None, Ga.data_ptr() if use_ln else None, N, DZ.data_ptr(),
+                   G.data_ptr() if use_ln else None, R, N, B, use_ln, act, st)
+    (yref * torch.tensor(dy.astype(np.float64)).reshape(E, B, N)).sum().backward()
+    torch.cuda.synchronize()
+    close(DZ.cpu().numpy(), zt.grad.numpy().reshape(R, N), rtol=1e-4, what="ln bwd dz")
+    if use_ln:
+        # column sums: dbeta = sum g, dgamma = sum g*xhat, dbias = sum dz
+        dbe = torch.zeros((E, N), device=dev); dga = torch.zeros((E, N), device=dev); dbi = torch.zeros((E, N), device=dev)
+        ops.colsum(G.data_ptr(), dbe.data_ptr(), E, B, N, N, N, st, x1=DZ.data_ptr(), out1=dbi.data_ptr(),
+                   x2=G.data_ptr(), mul2=XH.data_ptr(), out2=dga.data_ptr())
+        torch.cuda.synchronize()
+        g = G.cpu().numpy().astype(np.float64).reshape(E, B, N)
+        xh = XH.cpu().numpy().astype(np.float64).reshape(E, B, N)
+        close(dbe.cpu().numpy(), g.sum(1), what="dbeta")
+        close(dga.cpu().numpy(), (g * xh).sum(1), what="dgamma")
+        close(dbi.cpu().numpy(), zt.grad.numpy().sum(1), rtol=1e-4, what="dbias")
+
+
+def test_rowdot_and_rank1_bwd(dev):
+    ops = _ops()
+    rng = np.random.default_rng(4)
+    st = ops.current_stream()
+    E, B, N = 4, 33, 256
+    h = np.maximum(rng.standard_normal((E * B, N)), 0).astype(np.float32)
+    w = rng.standard_normal((E, N)).astype(np.float32); b = rng.standard_normal(E).astype(np.float32)
+    H, W, Bi = dv(h, dev), dv(w, dev), dv(b, dev)
+    Q = torch.zeros(E * B, device=dev)
+    ops.rowdot(H.data_ptr(), W.data_ptr(), Bi.data_ptr(), Q.data_ptr(), E * B, N, B, st)
+    torch.cuda.synchronize()
+    ref = np.einsum("ebn,en->eb", h.reshape(E, B, N).astype(np.float64), w.astype(np.float64)) + b[:, None]
+    close(Q.cpu().numpy().reshape(E, B), ref, what="rowdot")
+    # rank-1 backward form without LN: dz = dq[r] * w[e][n] * relu'(h)
+    dq = rng.standard_normal(E * B).astype(np.float32)
+    DQ = dv(dq, dev); DZ = torch.zeros((E * B, N), device=dev)
+    ops.ln_act_bwd(None, 0, DQ.data_ptr(), W.data_ptr(), N, H.data_ptr(), N, None, None, None, 0, DZ.data_ptr(), None,
+                   E * B, N, B, False, 1, st)
+    torch.cuda.synchronize()
+    ref = dq.reshape(E, B, 1) * w[:, None, :] * (h.reshape(E, B, N) > 0)
+    close(DZ.cpu().numpy().reshape(E, B, N), ref, what="rank1 bwd")
+    # weighted column sum: dw3[e][n] = sum_b dq[e,b] h[e,b,n]
+    out = torch.zeros((E, N), device=dev)
+    ops.colsum(H.data_ptr(), out.data_ptr(), E, B, N, N, N, st, w=DQ.data_ptr())
+    torch.cuda.synchronize()
+    close(out.cpu().numpy(), np.einsum("eb,ebn->en", dq.reshape(E, B).astype(np.float64),
+                                       h.reshape(E, B, N).astype(np.float64)), what="weighted colsum")
+
+
+# ---------------------------------------------------------------------------------- SLE
+@pytest.mark.parametrize("B,HW,C", [(5, 49, 256), (3, 30, 32), (2, 7, 70)])
+def test_sle(dev, B, HW, C):
+    ops = _ops()
+    rng = np.random.default_rng(5)
+    st = ops.current_stream()
+    feat = np.maximum(rng.standard_normal((B, HW, C)), 0).astype(np.float32)
+    ker = rng.standard_normal((HW, C, 8)).astype(np.float32)
+    Fe, Ke = dv(feat, dev), dv(ker, dev)
+    ldo = 2 * C * 8
+    out = torch.zeros((B, ldo), device=dev)
+    ops.sle_fwd(Fe.data_ptr(), Ke.data_ptr(), out.data_ptr() + C * 8 * 4, ldo, B, HW, C, 8, st)
+    torch.cuda.synchronize()
+    ref = np.einsum("bhc,hcf->bcf", feat.astype(np.float64), ker.astype(np.float64)).reshape(B, -1)
+    close(out.cpu().numpy()[:, C * 8:], ref, what="sle fwd")
+    assert float(out[:, :C * 8].abs().max()) == 0.0
+    dout = rng.standard_normal((B, ldo)).astype(np.float32)
+    DO = dv(dout, dev)
+    dfeat = torch.zeros((B, HW, C), device=dev); dker = torch.zeros((HW, C, 8), device=dev)
+    ops.sle_bwd(DO.data_ptr() + C * 8 * 4, ldo, Ke.data_ptr(), Fe.data_ptr(), dfeat.data_ptr(), dker.data_ptr(), B, HW,
+                C, 8, st)
+    torch.cuda.synchronize()
+    d = dout[:, C * 8:].reshape(B, C, 8).astype(np.float64)
+    close(dfeat.cpu().numpy(), np.einsum("bcf,hcf->bhc", d, ker.astype(np.float64)) * (feat > 0), what="sle dfeat")
+    close(dker.cpu().numpy(), np.einsum("bhc,bcf->hcf", feat.astype(np.float64), d), what="sle dker")
+
+
+# ---------------------------------------------------------------------------------- RNG, crop, gather
+def test_crop_offsets_bit_exact(dev):
+    from oracle import learner as ol, prng
+    ops = _ops()
+    st = ops.current_stream()
+    key = prng.split(prng.prng_key(42))[1]
+    n = 777
+    out = torch.zeros((n, 2), dtype=torch.int32, device=dev)
+    ops.crop_offsets(key, n, 0, n, 4, out.data_ptr(), st)
+    torch.cuda.synchronize()
+    ref = ol.crop_offsets(key, n)           # scalar restatement
+    assert np.array_equal(out.cpu().numpy(), ref)
+    assert np.array_equal(ol.crop_offsets_fast(key, n), ref)
+    # a shard of a larger global batch reproduces the global stream
+    sh = torch.zeros((100, 2), dtype=torch.int32, device=dev)
+    ops.crop_offsets(key, 100, 300, n, 4, sh.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert np.array_equal(sh.cpu().numpy(), ref[300:400])
+    assert ref.min() == 0 and ref.max() == 8
+
+
+@pytest.mark.parametrize("S", [3, 1])
+def test_gather_crop_bit_exact(dev, S):
+    from oracle import learner as ol
+    ops = _ops()
+    st = ops.current_stream()
+    rng = np.random.default_rng(6)
+    cap, H, W, n = 64, 128, 128, 24
+    frames = rng.integers(0, 256, size=(cap, H, W, 3), dtype=np.uint8)
+    indx = rng.integers(S, cap, size=n).astype(np.int64)
+    indx[0] = S            # lowest valid
+    indx[1] = cap - 1
+    indx[2] = 0            # demo-style index below S: wraps like numpy negative indexing (quirk C.7)
+    offs = rng.integers(0, 9, size=(2, n, 2)).astype(np.int32)
+    offs[0, 3] = (0, 0); offs[1, 3] = (8, 8); offs[0, 4] = (0, 8); offs[1, 4] = (8, 0); offs[0, 5] = (4, 4)
+    win = np.lib.stride_tricks.sliding_window_view(frames, S + 1, axis=0)[indx - S]     # (n,H,W,3,S+1)
+    ref_obs = ol.random_crop_batch(win[..., :-1], offs[0])
+    ref_nxt = ol.random_crop_batch(win[..., 1:], offs[1])
+    Fr, Ix, Of = dv(frames, dev), dv(indx, dev), dv(offs, dev)
+    o1 = torch.zeros((n, H, W, 3 * S), dtype=torch.uint8, device=dev); o2 = torch.zeros_like(o1)
+    ops.gather_crop_frames(Fr.data_ptr(), cap, Ix.data_ptr(), Of[0].data_ptr(), Of[1].data_ptr(), o1.data_ptr(),
+                           o2.data_ptr(), n, H, W, S, 4, st)
+    torch.cuda.synchronize()
+    assert np.array_equal(o1.cpu().numpy().reshape(n, H, W, 3, S), ref_obs)
+    assert np.array_equal(o2.cpu().numpy().reshape(n, H, W, 3, S), ref_nxt)
+    # packed source
+    Pk = dv(np.ascontiguousarray(win), dev)
+    o1.zero_(); o2.zero_()
+    ops.gather_crop_packed(Pk.data_ptr(), Of[0].data_ptr(), Of[1].data_ptr(), o1.data_ptr(), o2.data_ptr(), n, H, W, S,
+                           4, st)
+    torch.cuda.synchronize()
+    assert np.array_equal(o1.cpu().numpy().reshape(n, H, W, 3, S), ref_obs)
+    assert np.array_equal(o2.cpu().numpy().reshape(n, H, W, 3, S), ref_nxt)
+    # plain window gather
+    wout = torch.zeros((n, H, W, 3, S + 1), dtype=torch.uint8, device=dev)
+    ops.gather_window(Fr.data_ptr(), cap, Ix.data_ptr(), wout.data_ptr(), n, H * W * 3, S, st)
+    torch.cuda.synchronize()
+    assert np.array_equal(wout.cpu().numpy(), win)
+
+
+def test_tanh_gaussian(dev):
+    from oracle import learner as ol, prng
+    ops = _ops()
+    st = ops.current_stream()
+    rng = np.random.default_rng(7)
+    B, A = 256, 7
+    ms = rng.standard_normal((B, 2 * A)).astype(np.float32)
+    ms[:, A:] *= 3
+    ms[0, A] = 5.0; ms[1, A] = -25.0      # clipped log-stds
+    MS = dv(ms, dev)
+    act = torch.zeros((B, A + 3), device=dev); xp = torch.zeros((B, A), device=dev)
+    ep = torch.zeros((B, A), device=dev); lp = torch.zeros((B,), device=dev)
+    key = prng.split(prng.prng_key(5))[0]
+    ops.tanh_gaussian_fwd(MS.data_ptr(), MS.data_ptr() + 4 * A, 2 * A, act.data_ptr(), A + 3, xp.data_ptr(),
+                          ep.data_ptr(), lp.data_ptr(), B, A, key, 0, B, False, st)
+    torch.cuda.synchronize()
+    eps_ref = prng.normal(key, (B, A))
+    close(ep.cpu().numpy(), eps_ref, rtol=2e-6, what="normal stream")
+    mean = torch.tensor(ms[:, :A], dtype=torch.float64, requires_grad=True)
+    raw = torch.tensor(ms[:, A:], dtype=torch.float64, requires_grad=True)
+    lstd = torch.clamp(raw, -20.0, 2.0)
+    x = mean + torch.exp(lstd) * torch.tensor(eps_ref, dtype=torch.float64)
+    a = torch.tanh(x)
+    logp = ol.tanh_normal_log_prob(mean, lstd, x)
+    close(act.cpu().numpy()[:, :A], a.detach().numpy(), what="actions")
+    # log-prob: the reference evaluates (x - mean)/sigma in float32 (cancels to 0 when sigma = e^-20),
+    # so compare with the float32 oracle, not the float64 one
+    m32 = torch.tensor(ms[:, :A]); l32 = torch.clamp(torch.tensor(ms[:, A:]), -20.0, 2.0)
+    x32 = m32 + torch.exp(l32) * torch.tensor(eps_ref)
+    close(lp.cpu().numpy(), ol.tanh_normal_log_prob(m32, l32, x32).numpy(), rtol=1e-5, what="log prob")
+    # shard == slice of the global stream
+    sh = torch.zeros((64, A), device=dev); a2 = torch.zeros((64, A), device=dev)
+    ops.tanh_gaussian_fwd(MS.data_ptr() + 64 * 2 * A * 4, MS.data_ptr() + 64 * 2 * A * 4 + 4 * A, 2 * A, a2.data_ptr(),
+                          A, None, sh.data_ptr(), None, 64, A, key, 64, B, False, st)
+    torch.cuda.synchronize()
+    assert np.array_equal(sh.cpu().numpy(), ep.cpu().numpy()[64:128])
+    # backward: L = mean(alpha*logp) + sum(a * c)  with da = c
+    alpha = 0.37
+    c = rng.standard_normal((B, A)).astype(np.float32)
+    loss = (alpha * logp).mean() + (a * torch.tensor(c, dtype=torch.float64)).sum()
+    loss.backward()
+    LT = dv(np.array([math.log(alpha)], dtype=np.float32), dev)
+    DA = dv(c, dev)
+    dms = torch.zeros((B, 2 * A), device=dev)
+    ops.tanh_gaussian_bwd(act.data_ptr(), A + 3, ep.data_ptr(), MS.data_ptr() + 4 * A, 2 * A, DA.data_ptr(), A,
+                          LT.data_ptr(), 1.0 / B, dms.data_ptr(), dms.data_ptr() + 4 * A, 2 * A, B, A, st)
+    torch.cuda.synchronize()
+    close(dms.cpu().numpy()[:, :A], mean.grad.numpy(), rtol=1e-4, what="dmean")
+    close(dms.cpu().numpy()[:, A:], raw.grad.numpy(), rtol=1e-4, what="dlogstd")
+    # deterministic mode = tanh(mean)
+    ops.tanh_gaussian_fwd(MS.data_ptr(), MS.data_ptr() + 4 * A, 2 * A, act.data_ptr(), A + 3, None, None, None, B, A,
+                          key, 0, B, True, st)
+    torch.cuda.synchronize()
+    close(act.cpu().numpy()[:, :A], np.tanh(ms[:, :A].astype(np.float64)), what="mode")
+
+
+def test_td_loss_actor_loss_adam_temperature(dev):
+    from oracle import learner as ol
+    ops = _ops()
+    st = ops.current_stream()
+    rng = np.random.default_rng(8)
+    E, Em, B = 10, 2, 256
+    nq = rng.standard_normal((Em, B)).astype(np.float32); q = rng.standard_normal((E, B)).astype(np.float32)
+    rew = rng.standard_normal(B).astype(np.float32); msk = (rng.random(B) < 0.9).astype(np.float32)
+    nlp = rng.standard_normal(B).astype(np.float32)
+    lt = np.array([math.log(0.2)], dtype=np.float32)
+    NQ, Q, R, M, NLP, LT = (dv(a, dev) for a in (nq, q, rew, msk, nlp, lt))
+    tgt = torch.zeros(B, device=dev); dq = torch.zeros((E, B), device=dev); info = torch.zeros(4, device=dev)
+    for backup in (False, True):
+        ops.td_loss(NQ.data_ptr(), Em, R.data_ptr(), M.data_ptr(), NLP.data_ptr() if backup else None, LT.data_ptr(),
+                    0.99, Q.data_ptr(), E, B, 1.0 / (E * B), tgt.data_ptr(), dq.data_ptr(), info.data_ptr(), st)
+        torch.cuda.synchronize()
+        t = rew + 0.99 * msk * nq.min(0)
+        if backup:
+            t = t - 0.99 * msk * 0.2 * nlp
+        close(tgt.cpu().numpy(), t, what="target")
+        close(dq.cpu().numpy(), 2 * (q - t) / (E * B), what="dq")
+        close(info.cpu().numpy()[0] / (E * B), ((q - t) ** 2).mean(), what="loss")
+        close(info.cpu().numpy()[1] / (E * B), q.mean(), rtol=1e-4, what="q mean")
+    ops.actor_loss(Q.data_ptr(), E, B, NLP.data_ptr(), LT.data_ptr(), info.data_ptr(), st)
+    torch.cuda.synchronize()
+    close(info.cpu().numpy()[0] / B, (nlp * 0.2 - q.mean(0)).mean(), rtol=1e-4, what="actor loss")
+    close(info.cpu().numpy()[1] / B, nlp.mean(), rtol=1e-4, what="sum logp")
+    # Adam + Polyak against the oracle's optax restatement, 3 steps, odd length (tail path)
+    n = 1027
+    p0 = rng.standard_normal(n).astype(np.float32); t0 = rng.standard_normal(n).astype(np.float32)
+    ts = dict(params=dict(w=p0.copy()), mu=dict(w=np.zeros(n, np.float32)), nu=dict(w=np.zeros(n, np.float32)), count=0)
+    tgt_ref = dict(w=t0.copy())
+    P, Mo, V, T = dv(p0, dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev), dv(t0, dev)
+    for step in range(1, 4):
+        g = rng.standard_normal(n).astype(np.float32)
+        ts = ol.adam_step(ts, dict(w=g), 3e-4)
+        tgt_ref = ol.polyak(ts["params"], tgt_ref, 0.005)
+        bc1 = np.float32(1) - np.float32(0.9) ** np.float32(step)
+        bc2 = np.float32(1) - np.float32(0.999) ** np.float32(step)
+        ops.adam_polyak(P.data_ptr(), Mo.data_ptr(), V.data_ptr(), dv(g, dev).data_ptr(), T.data_ptr(), n, 3e-4, 0.9,
+                        0.999, 1e-8, bc1, bc2, 0.005, 1.0, st)
+        torch.cuda.synchronize()
+    close(P.cpu().numpy(), ts["params"]["w"], rtol=1e-6, what="adam params")
+    close(T.cpu().numpy(), tgt_ref["w"], rtol=1e-6, what="polyak")
+    # temperature
+    state = dv(np.array([math.log(0.1), 0, 0], dtype=np.float32), dev)
+    sl = dv(np.array([-3.0 * B], dtype=np.float32), dev)     # entropy = 3.0
+    out = torch.zeros(3, device=dev)
+    ops.temperature_update(state.data_ptr(), sl.data_ptr(), 1.0 / B, -3.5, 3e-4, 0.9, 0.999, 1e-8, 0.1, 0.001, out.data_ptr(), st)
+    torch.cuda.synchronize()
+    st0 = dict(rng=None, temp=dict(params=dict(log_temp=np.float32(math.log(0.1))), mu=dict(log_temp=np.float32(0)),
+                                   nu=dict(log_temp=np.float32(0)), count=0))
+    new, tinfo = ol.update_temperature(st0, dict(target_entropy=-3.5, temp_lr=3e-4), 3.0)
+    close(out.cpu().numpy()[:2], [tinfo["temperature"], tinfo["temperature_loss"]], rtol=1e-5, what="temp info")
+    close(state.cpu().numpy()[0], new["temp"]["params"]["log_temp"], rtol=1e-6, what="log_temp")
+
+
+def test_error_channel(dev):
+    ops = _ops()
+    with pytest.raises(ValueError):
+        ops.fill(0, 1.0, 10, 0)
+    with pytest.raises(ValueError):
+        ops.conv2d_fwd([1] * 9, [1] * 9, [1] * 9, [1] * 9, False, 1, 8, 8, 3, 3, 3, 1, 4, True, 0)
