@@ -32,7 +32,7 @@ _SIGS = {
     "serl_ln_act_fwd": [c_p, c_i, c_ll, c_i, c_p, c_p, c_p, c_ll, c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
     "serl_ln_act_bwd": [c_p, c_i, c_p, c_p, c_ll, c_p, c_i, c_p, c_p, c_p, c_ll, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
     "serl_colsum": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_ll, c_p],
-    "serl_rowdot": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
+    "serl_rowdot": [c_p, c_p, c_ll, c_p, c_ll, c_p, c_i, c_i, c_i, c_p],
     "serl_copy2d": [c_p, c_i, c_p, c_i, c_i, c_i, c_p],
     "serl_fill": [c_p, c_f, c_ll, c_p],
     "serl_tanh_gaussian_fwd": [c_p, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_u, c_u, c_i, c_i, c_i, c_p],
@@ -43,10 +43,13 @@ _SIGS = {
     "serl_temperature_update": [c_p, c_p, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p, c_p],
     "serl_sle_fwd": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
     "serl_sle_bwd": [c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
-    "serl_gather_crop_frames": [c_p, c_ll, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
-    "serl_gather_crop_packed": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
+    "serl_gather_crop_frames": [c_p, c_ll, c_p, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
+    "serl_gather_crop_packed": [c_p, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
     "serl_gather_window": [c_p, c_ll, c_p, c_p, c_i, c_i, c_i, c_p],
     "serl_crop_offsets": [c_u, c_u, c_i, c_i, c_i, c_i, c_p, c_p],
+    "serl_prng_split": [c_u, c_u, c_i, c_p],
+    "serl_prng_bits": [c_u, c_u, c_i, c_p],
+    "serl_prng_choice": [c_u, c_u, c_i, c_i, c_p],
 }
 _RESTYPE = {"serl_conv2d_wgrad_workspace_bytes": c_ll}
 

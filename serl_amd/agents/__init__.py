@@ -1,0 +1,6 @@
+from .agent import Agent
+from .drq.drq_learner import DrQLearner
+from .sac.sac_learner import SACLearner
+from .train_state import TempState, TrainState
+
+__all__ = ["Agent", "SACLearner", "DrQLearner", "TrainState", "TempState"]

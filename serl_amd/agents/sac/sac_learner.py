@@ -1,0 +1,257 @@
+"""SAC / REDQ / RLPD learner on MI355X (mirrors serl/agents/sac/sac_learner.py).
+
+`create` / `update(batch, utd_ratio)` keep the reference signatures and semantics:
+  * UTD loop over contiguous minibatch slices, critic step each, then ONE actor step and ONE
+    temperature step on the last minibatch (sac_learner.py:221-238)
+  * critic step: a' ~ pi(s'), REDQ subsample of the target ensemble, min-Q TD target (optional entropy
+    backup), MSE over ensemble x batch, Adam, Polyak on all critic params (sac_learner.py:160-219)
+  * actor step: mean-over-ensemble Q, alpha*logp - Q (sac_learner.py:120-144); temperature (146-158)
+  * RNG: the jax split chain of SURVEY.md appendix B, evaluated on the host (native threefry)
+All tensor math runs in hand-written HIP kernels (serl_amd.ops); Python only sequences launches.
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from ... import ops, prng
+from ...frozen_dict import FrozenDict
+from ...networks import modules as nn
+from ...networks.modules import Workspace
+from ...networks.params import ParamStore
+from ...networks.spec import NetConfig, actor_layout, critic_head_prefix, critic_layout, init_tree
+from ..agent import Agent
+from ..train_state import ADAM_B1, ADAM_B2, ADAM_EPS, TempState, TrainState, bias_corrections
+
+
+def _device(device):
+    if device is not None:
+        return torch.device(device)
+    if not torch.cuda.is_available():
+        raise RuntimeError("serl_amd needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _to_dev(x, dev, dtype):
+    if isinstance(x, torch.Tensor):
+        return x.to(device=dev, dtype=dtype).contiguous()
+    return torch.from_numpy(np.ascontiguousarray(np.asarray(x), dtype=None)).to(dev).to(dtype).contiguous()
+
+
+class SACLearner(Agent):
+    """State-based SAC learner. Fields as in the reference dataclass (sac_learner.py:19-30)."""
+
+    # ------------------------------------------------------------------ construction
+    @classmethod
+    def create(cls, seed: int, observation_space, action_space, actor_lr: float = 3e-4, critic_lr: float = 3e-4,
+               temp_lr: float = 3e-4, hidden_dims: Sequence[int] = (256, 256), discount: float = 0.99,
+               tau: float = 0.005, num_qs: int = 2, num_min_qs: Optional[int] = None,
+               critic_dropout_rate: Optional[float] = None, critic_layer_norm: bool = False,
+               target_entropy: Optional[float] = None, init_temperature: float = 1.0, backup_entropy: bool = True,
+               device=None, dist=None):
+        action_dim = int(action_space.shape[-1])
+        cfg = NetConfig(action_dim=action_dim, hidden_dims=tuple(int(h) for h in hidden_dims), num_qs=int(num_qs),
+                        critic_layer_norm=bool(critic_layer_norm), obs_dim=int(observation_space.shape[-1]))
+        return cls._build(cfg, seed, actor_lr, critic_lr, temp_lr, discount, tau, num_min_qs, critic_dropout_rate,
+                          target_entropy, init_temperature, backup_entropy, device, dist)
+
+    @classmethod
+    def _build(cls, cfg, seed, actor_lr, critic_lr, temp_lr, discount, tau, num_min_qs, critic_dropout_rate,
+               target_entropy, init_temperature, backup_entropy, device, dist):
+        if critic_dropout_rate:
+            raise NotImplementedError("critic dropout is not used by any SERL config and is not implemented")
+        dev = _device(device)
+        if target_entropy is None:
+            target_entropy = -cfg.action_dim / 2                        # sac_learner.py:60-61
+        rng = prng.PRNGKey(seed)
+        rng, actor_key, critic_key, temp_key = prng.split(rng, 4)       # :63-64
+        al, cl = actor_layout(cfg), critic_layout(cfg)
+        actor_store = ParamStore.from_tree(al, init_tree(al, [int(actor_key[0]), int(actor_key[1])]), dev)
+        critic_store = ParamStore.from_tree(cl, init_tree(cl, [int(critic_key[0]), int(critic_key[1])]), dev)
+        self = cls.__new__(cls)
+        self.rng = rng
+        self.actor = TrainState.create(actor_store, actor_lr)
+        self.critic = TrainState.create(critic_store, critic_lr)
+        self.target_critic = TrainState.create(critic_store.clone(), None)     # same initial params (:92-96)
+        self.temp = TempState.create(init_temperature, temp_lr, dev)
+        self.tau, self.discount, self.target_entropy = float(tau), float(discount), float(target_entropy)
+        self.num_qs, self.num_min_qs, self.backup_entropy = cfg.num_qs, num_min_qs, bool(backup_entropy)
+        self._cfg = cfg
+        self._shared = {"dist": dist}
+        return self
+
+    # ------------------------------------------------------------------ helpers
+    @property
+    def _dist(self):
+        return self._shared.get("dist")
+
+    def _ws(self, B) -> Workspace:
+        key = ("ws_update", B)
+        ws = self._shared.get(key)
+        if ws is None:
+            ws = self._shared[key] = Workspace(self.actor.store.flat.device)
+        return ws
+
+    def _grads(self, name, like: ParamStore) -> ParamStore:
+        g = self._shared.get(name)
+        if g is None:
+            g = self._shared[name] = like.zeros_like()
+        return g
+
+    def _target_members(self, key):
+        """REDQ subsample (serl/networks/ensemble.py:25-37) -> (first member, member stride, count)."""
+        E = self.num_qs
+        if self.num_min_qs is None:
+            return 0, 1, E, None
+        idx = prng.choice_no_replace(key, E, int(self.num_min_qs))
+        if len(idx) == 1:
+            return int(idx[0]), 1, 1, idx
+        d = int(idx[1]) - int(idx[0])
+        if all(int(idx[i + 1]) - int(idx[i]) == d for i in range(len(idx) - 1)):
+            return int(idx[0]), d, len(idx), idx
+        return None, None, len(idx), idx
+
+    def _gathered_target(self, idx):
+        """General num_min_qs > 2: copy the chosen members into a scratch store (rare path)."""
+        cfg, src = self._cfg, self.target_critic.store
+        scratch = self._shared.get("tgt_scratch")
+        if scratch is None:
+            scratch = self._shared["tgt_scratch"] = src.zeros_like()
+        pre = critic_head_prefix(cfg)
+        st = ops.current_stream()
+        for path, (off, shape) in src.layout.entries.items():
+            if path[:len(pre)] != pre:
+                continue
+            per = int(np.prod(shape[1:]))
+            for j, m in enumerate(idx):
+                ops.copy2d(scratch.base + 4 * (off + j * per), per, src.base + 4 * (off + int(m) * per), per, 1, per, st)
+        return scratch
+
+    # ------------------------------------------------------------------ feature stage (overridden for pixels)
+    def _prepare(self, batch, n):
+        dev = self.actor.store.flat.device
+        f32 = torch.float32
+        return dict(obs=_to_dev(batch["observations"], dev, f32).reshape(n, -1),
+                    next_obs=_to_dev(batch["next_observations"], dev, f32).reshape(n, -1))
+
+    def _features(self, passes, feats, lo, B, ws, st, save_tag=None):
+        """passes: list of (tag, store, which) -> fills z_<tag>[:, :latent]. State-based: a strided copy."""
+        cfg = self._cfg
+        ldz = cfg.latent + cfg.action_dim
+        for tag, _store, which in passes:
+            src = feats["next_obs" if which == "next" else "obs"]
+            ops.copy2d(ws.ptr(f"z{tag}", (B, ldz)), ldz, src.data_ptr() + 4 * lo * cfg.obs_dim, cfg.obs_dim, B,
+                       cfg.obs_dim, st)
+
+    def _features_bwd(self, tag, store, grads, feats, lo, B, ws, st, dz_ptr, lddz, need_encoder):
+        return  # no trainable feature stage for state inputs
+
+    # ------------------------------------------------------------------ update
+    def update(self, batch, utd_ratio: int):
+        n = len(batch["rewards"])
+        assert n % utd_ratio == 0                                         # sac_learner.py:228
+        feats = self._prepare(batch, n)
+        return self._update_prepared(batch, feats, n, utd_ratio, self.actor.clone())
+
+    def _update_prepared(self, batch, feats, n, utd_ratio, actor):
+        cfg = self._cfg
+        dev = self.actor.store.flat.device
+        f32 = torch.float32
+        B = n // utd_ratio
+        A = cfg.action_dim
+        ldz = cfg.latent + A
+        E = cfg.num_qs
+        dist = self._dist
+        world = dist.world_size if dist is not None else 1
+        rank = dist.rank if dist is not None else 0
+        Bg = B * world
+        st = ops.current_stream()
+        ws = self._ws(B)
+
+        actions = _to_dev(batch["actions"], dev, f32).reshape(n, A)
+        rewards = _to_dev(batch["rewards"], dev, f32).reshape(n)
+        masks = _to_dev(batch["masks"], dev, f32).reshape(n)
+
+        # functional semantics: step fresh copies (`actor` is already one), leave `self` untouched
+        critic, target, temp = self.critic.clone(), self.target_critic.clone(), self.temp.clone()
+        cgr = self._grads("critic_grads", critic.store)
+        agr = self._grads("actor_grads", actor.store)
+        info = ws.tensor("info", (8,))
+        zA, zT, zC = (ws.ptr(f"z{t}", (B, ldz)) for t in "ATC")
+        log_temp = temp.buf.data_ptr()
+        rng = self.rng
+
+        for i in range(utd_ratio):
+            lo = i * B
+            # ---- critic step (sac_learner.py:160-219)
+            key_act, rng = prng.split(rng)
+            key_sub, rng = prng.split(rng)
+            _, rng = prng.split(rng)                       # target dropout key (consumed, unused)
+            _, rng = prng.split(rng)                       # critic dropout key
+            m0, mstride, emin, idx = self._target_members(key_sub)
+            tstore = target.store
+            if m0 is None:
+                tstore, m0, mstride = self._gathered_target(idx), 0, 1
+            self._features([("A", actor.store, "next"), ("T", target.store, "next"), ("C", critic.store, "obs")],
+                           feats, lo, B, ws, st, save_tag="C")
+            nlogp = nn.policy_fwd(cfg, "A", actor.store, zA, ldz, B, ws, st, key_act, rank * B, Bg,
+                                  zT + 4 * cfg.latent, ldz, want_logp=self.backup_entropy)
+            next_q = nn.ensemble_fwd(cfg, "T", tstore, m0, mstride, emin, zT, ldz, B, ws, st, save=False)
+            ops.copy2d(zC + 4 * cfg.latent, ldz, actions.data_ptr() + 4 * lo * A, A, B, A, st)
+            q = nn.ensemble_fwd(cfg, "C", critic.store, 0, 1, E, zC, ldz, B, ws, st, save=True)
+            dq = ws.ptr("dq", (E, B))
+            ops.td_loss(next_q, emin, rewards.data_ptr() + 4 * lo, masks.data_ptr() + 4 * lo,
+                        nlogp if self.backup_entropy else None, log_temp, self.discount, q, E, B, 1.0 / (E * Bg),
+                        ws.ptr("target_q", (B,)), dq, info.data_ptr(), st)
+            dinp = nn.ensemble_bwd(cfg, "C", critic.store, cgr, dq, zC, ldz, B, ws, st)
+            self._features_bwd("C", critic.store, cgr, feats, lo, B, ws, st, dinp, ldz, need_encoder=True)
+            if dist is not None:
+                dist.all_reduce_sum(cgr.flat)
+            critic.step += 1
+            bc1, bc2 = bias_corrections(critic.step)
+            ops.adam_polyak(critic.store.base, critic.mu.data_ptr(), critic.nu.data_ptr(), cgr.base,
+                            target.store.base, critic.store.flat.numel(), critic.lr, ADAM_B1, ADAM_B2, ADAM_EPS, bc1, bc2,
+                            self.tau, 1.0, st)
+
+        # ---- actor step on the last minibatch (sac_learner.py:120-144, 235)
+        lo = (utd_ratio - 1) * B
+        key_pi, rng = prng.split(rng)
+        _, rng = prng.split(rng)                           # critic dropout key
+        self._features([("A", actor.store, "obs"), ("C", critic.store, "obs")], feats, lo, B, ws, st, save_tag="A")
+        logp = nn.policy_fwd(cfg, "A", actor.store, zA, ldz, B, ws, st, key_pi, rank * B, Bg, zC + 4 * cfg.latent, ldz,
+                             save=True)
+        q = nn.ensemble_fwd(cfg, "C", critic.store, 0, 1, E, zC, ldz, B, ws, st, save=True)
+        ops.actor_loss(q, E, B, logp, log_temp, info.data_ptr() + 8, st)
+        dq = ws.ptr("dq", (E, B))
+        ops.fill(dq, -1.0 / (E * Bg), E * B, st)
+        dinp = nn.ensemble_bwd(cfg, "C", critic.store, None, dq, zC, ldz, B, ws, st)
+        A_ = cfg.action_dim
+        dms = ws.ptr("dms", (B, 2 * A_))
+        ms = ws.ptr("ms_A", (B, 2 * A_))
+        ops.tanh_gaussian_bwd(zC + 4 * cfg.latent, ldz, ws.ptr("eps_A", (B, A_)), ms + 4 * A_, 2 * A_,
+                              dinp + 4 * cfg.latent, ldz, log_temp, 1.0 / Bg, dms, dms + 4 * A_, 2 * A_, B, A_, st)
+        dz = nn.policy_bwd(cfg, "A", actor.store, agr, zA, ldz, B, ws, st, need_dz=cfg.pixel)
+        self._features_bwd("A", actor.store, agr, feats, lo, B, ws, st, dz, cfg.latent, need_encoder=False)
+        if dist is not None:
+            dist.all_reduce_sum(agr.flat)
+            dist.all_reduce_sum(info[:4])                   # loss / q / logp sums -> global before the temperature step
+        actor.step += 1
+        bc1, bc2 = bias_corrections(actor.step)
+        ops.adam_polyak(actor.store.base, actor.mu.data_ptr(), actor.nu.data_ptr(), agr.base, None,
+                        actor.store.flat.numel(), actor.lr, ADAM_B1, ADAM_B2, ADAM_EPS, bc1, bc2, 0.0, 1.0, st)
+        # ---- temperature (sac_learner.py:146-158, 236)
+        temp.step += 1
+        bc1, bc2 = bias_corrections(temp.step)
+        ops.temperature_update(temp.buf.data_ptr(), info.data_ptr() + 12, 1.0 / Bg, self.target_entropy, temp.lr,
+                               ADAM_B1, ADAM_B2, ADAM_EPS, bc1, bc2, info.data_ptr() + 16, st)
+
+        new_agent = self.replace(actor=actor, critic=critic, target_critic=target, temp=temp, rng=rng)
+        h = info.cpu().numpy()                              # one small D2H per update call
+        out = {
+            "actor_loss": float(h[2]) / Bg, "entropy": float(h[6]),
+            "critic_loss": float(h[0]) / (E * Bg), "q": float(h[1]) / (E * Bg),
+            "temperature": float(h[4]), "temperature_loss": float(h[5]),
+        }
+        return new_agent, out

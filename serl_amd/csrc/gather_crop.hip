@@ -15,34 +15,31 @@
 #define GC_TH 8
 
 struct GcArgs {
-  const unsigned char* src;   // FRAMES: (cap, H, W, 3)   PACKED: (n, H, W, 3, S+1)
+  const unsigned char* src;   // FRAMES: (cap, H, W, 3)   PACKED: (n, H, W, 3, T)
   const long long* indx;      // FRAMES only: (n) replay indices (window = rows indx-S .. indx)
-  const int* off_obs;         // (n, 2) int32 (dy, dx) in [0, 2*pad]
-  const int* off_next;
-  unsigned char* out_obs;     // (n, H, W, 3*S)
-  unsigned char* out_next;
-  int n, H, W, S, pad, cap;
+  const int* off;             // (n, 2) int32 (dy, dx) in [0, 2*pad]
+  unsigned char* out;         // (n, H, W, 3*S): out[.., c*S+s] = frame (t0 + s) of the window, shifted
+  int n, H, W, S, T, t0, pad, cap;
 };
 
 template <bool PACKED>
 __global__ __launch_bounds__(256) void gather_crop_kernel(const GcArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int j = blockIdx.x, which = blockIdx.y, y0 = blockIdx.z * GC_TH;
-  const int S = a.S, W = a.W, H = a.H;
+  const int j = blockIdx.x, y0 = blockIdx.y * GC_TH;
+  const int S = a.S, W = a.W, H = a.H, T = a.T;
   const int rowb = W * 3;                      // bytes of one source frame row
-  const int srow = PACKED ? rowb * (S + 1) : rowb;  // bytes of one staged source row
+  const int srow = PACKED ? rowb * T : rowb;   // bytes of one staged source row
   const int nsrc = PACKED ? 1 : S;             // staged planes
   unsigned char* s_src = smem;                                  // [nsrc][TH][srow]
   unsigned char* s_out = smem + nsrc * GC_TH * srow;            // [TH][rowb*S]
-  const int* off = which ? a.off_next : a.off_obs;
-  const int dy = off[2 * j] - a.pad, dx = off[2 * j + 1] - a.pad;
+  const int dy = a.off[2 * j] - a.pad, dx = a.off[2 * j + 1] - a.pad;
   const int rows = min(GC_TH, H - y0);
 
   // ---- phase 1: global -> LDS, 16 B per lane
   long long w0 = 0;
   if (!PACKED) {
-    w0 = a.indx[j] - S;
-    if (w0 < 0) w0 += a.cap - S;  // python negative index into the (cap - S)-long window view
+    w0 = a.indx[j] - (T - 1);
+    if (w0 < 0) w0 += a.cap - (T - 1);  // python negative index into the (cap - S)-long window view
   }
   const int vec_per_row = srow / 16;
   const int nvec = nsrc * rows * vec_per_row;
@@ -54,7 +51,7 @@ __global__ __launch_bounds__(256) void gather_crop_kernel(const GcArgs a) {
     sy = sy < 0 ? 0 : (sy >= H ? H - 1 : sy);
     const unsigned char* g;
     if (PACKED) g = a.src + ((long long)j * H + sy) * srow + q * 16;
-    else g = a.src + ((w0 + p + which) * H + sy) * (long long)rowb + q * 16;
+    else g = a.src + ((w0 + p + a.t0) * H + sy) * (long long)rowb + q * 16;
     *(uint4*)(s_src + (p * GC_TH + r) * srow + q * 16) = *(const uint4*)g;
   }
   __syncthreads();
@@ -68,9 +65,9 @@ __global__ __launch_bounds__(256) void gather_crop_kernel(const GcArgs a) {
     unsigned char* o = s_out + r * orow + x * 3 * S;
     for (int s = 0; s < S; ++s) {
       const unsigned char* sp;
-      if (PACKED) sp = s_src + r * srow + sx * 3 * (S + 1) + (s + which);
+      if (PACKED) sp = s_src + r * srow + sx * 3 * T + (s + a.t0);
       else sp = s_src + (s * GC_TH + r) * srow + sx * 3;
-      const int cs = PACKED ? (S + 1) : 1;
+      const int cs = PACKED ? T : 1;
       o[0 * S + s] = sp[0];
       o[1 * S + s] = sp[cs];
       o[2 * S + s] = sp[2 * cs];
@@ -79,46 +76,44 @@ __global__ __launch_bounds__(256) void gather_crop_kernel(const GcArgs a) {
   __syncthreads();
 
   // ---- phase 3: LDS -> global, 16 B per lane
-  unsigned char* out = (which ? a.out_next : a.out_obs) + ((long long)j * H + y0) * orow;
+  unsigned char* out = a.out + ((long long)j * H + y0) * orow;
   const int ovec = rows * orow / 16;
   for (int v = threadIdx.x; v < ovec; v += 256) *(uint4*)(out + v * 16) = *(const uint4*)(s_out + v * 16);
 }
 
 static int gc_launch(const GcArgs& a, bool packed, hipStream_t st) {
   const int rowb = a.W * 3;
+  SERL_CHECK_ARG(a.n >= 1 && a.S >= 1 && a.t0 >= 0 && a.t0 + a.S <= a.T, "gather_crop: frames t0..t0+S-1 outside the window");
   SERL_CHECK_ARG(rowb % 16 == 0, "gather_crop: W*3 must be a multiple of 16 bytes");
-  SERL_CHECK_ARG((rowb * a.S * GC_TH) % 16 == 0, "gather_crop: output row tile not 16-byte sized");
-  SERL_CHECK_ARG(((uintptr_t)a.src & 15) == 0 && ((uintptr_t)a.out_obs & 15) == 0 && ((uintptr_t)a.out_next & 15) == 0,
-                 "gather_crop: buffers must be 16-byte aligned");
+  SERL_CHECK_ARG(((uintptr_t)a.src & 15) == 0 && ((uintptr_t)a.out & 15) == 0, "gather_crop: buffers must be 16-byte aligned");
   SERL_CHECK_ARG(a.H % GC_TH == 0, "gather_crop: H must be a multiple of %d", GC_TH);
-  const int srow = packed ? rowb * (a.S + 1) : rowb;
+  const int srow = packed ? rowb * a.T : rowb;
   const int nsrc = packed ? 1 : a.S;
   const size_t lds = (size_t)nsrc * GC_TH * srow + (size_t)GC_TH * rowb * a.S;
   SERL_CHECK_ARG(lds <= 64 * 1024, "gather_crop: tile needs %zu B of LDS", lds);
-  dim3 grid(a.n, 2, a.H / GC_TH);
+  dim3 grid(a.n, a.H / GC_TH);
   if (packed) hipLaunchKernelGGL(gather_crop_kernel<true>, grid, dim3(256), lds, st, a);
   else hipLaunchKernelGGL(gather_crop_kernel<false>, grid, dim3(256), lds, st, a);
   SERL_CHECK_LAUNCH("gather_crop");
   return SERL_OK;
 }
 
-// frames: device-resident frame store (cap,H,W,3); indx: device int64 (n).
-extern "C" int serl_gather_crop_frames(const unsigned char* frames, long long cap, const long long* indx,
-                                       const int* off_obs, const int* off_next, unsigned char* out_obs,
-                                       unsigned char* out_next, int n, int H, int W, int S, int pad, void* stream) {
-  SERL_CHECK_ARG(frames && indx && off_obs && off_next && out_obs && out_next, "gather_crop_frames: null pointer");
-  SERL_CHECK_ARG(n >= 1 && S >= 1 && cap > S && cap < (1ll << 31), "gather_crop_frames: bad sizes");
-  GcArgs a{frames, indx, off_obs, off_next, out_obs, out_next, n, H, W, S, pad, (int)cap};
+// frames: device-resident frame store (cap,H,W,3); indx: device int64 (n); the window of sample j is
+// store rows indx[j]-S_win .. indx[j] (S_win+1 = T frames); output takes frames t0 .. t0+S-1 of it.
+extern "C" int serl_gather_crop_frames(const unsigned char* frames, long long cap, const long long* indx, int T, int t0,
+                                       const int* off, unsigned char* out, int n, int H, int W, int S, int pad,
+                                       void* stream) {
+  SERL_CHECK_ARG(frames && indx && off && out, "gather_crop_frames: null pointer");
+  SERL_CHECK_ARG(cap > T && cap < (1ll << 31), "gather_crop_frames: bad capacity");
+  GcArgs a{frames, indx, off, out, n, H, W, S, T, t0, pad, (int)cap};
   return gc_launch(a, false, (hipStream_t)stream);
 }
 
-// packed: (n,H,W,3,S+1) as returned by sample(pack_obs_and_next_obs=True).
-extern "C" int serl_gather_crop_packed(const unsigned char* packed, const int* off_obs, const int* off_next,
-                                       unsigned char* out_obs, unsigned char* out_next, int n, int H, int W, int S,
-                                       int pad, void* stream) {
-  SERL_CHECK_ARG(packed && off_obs && off_next && out_obs && out_next, "gather_crop_packed: null pointer");
-  SERL_CHECK_ARG(n >= 1 && S >= 1, "gather_crop_packed: bad sizes");
-  GcArgs a{packed, nullptr, off_obs, off_next, out_obs, out_next, n, H, W, S, pad, 0};
+// src: (n,H,W,3,T) stacked frames (T = S+1 for sample(pack_obs_and_next_obs=True), T = S when unpacked).
+extern "C" int serl_gather_crop_packed(const unsigned char* src, int T, int t0, const int* off, unsigned char* out,
+                                       int n, int H, int W, int S, int pad, void* stream) {
+  SERL_CHECK_ARG(src && off && out, "gather_crop_packed: null pointer");
+  GcArgs a{src, nullptr, off, out, n, H, W, S, T, t0, pad, 0};
   return gc_launch(a, true, (hipStream_t)stream);
 }
 

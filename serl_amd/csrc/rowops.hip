@@ -210,21 +210,21 @@ extern "C" int serl_colsum(const float* x0, const float* w, const float* mul, fl
 }
 
 // ------------------------------------------------------------------ Dense(1) head: q[r] = h[r,:].w[e,:] + b[e]
-__global__ __launch_bounds__(256) void rowdot_kernel(const float* h, const float* w, const float* b, float* q, int R,
-                                                     int N, int rows_per_group) {
+__global__ __launch_bounds__(256) void rowdot_kernel(const float* h, const float* w, long long w_gs, const float* b,
+                                                     long long b_gs, float* q, int R, int N, int rows_per_group) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= R) return;
   const int e = row / rows_per_group;
   float s = 0.f;
-  for (int n = lane; n < N; n += 64) s += h[(long long)row * N + n] * w[(long long)e * N + n];
+  for (int n = lane; n < N; n += 64) s += h[(long long)row * N + n] * w[e * w_gs + n];
   s = wave_sum(s);
-  if (lane == 0) q[row] = s + b[e];
+  if (lane == 0) q[row] = s + b[e * b_gs];
 }
-extern "C" int serl_rowdot(const float* h, const float* w, const float* b, float* q, int R, int N, int rows_per_group,
-                           void* stream) {
+extern "C" int serl_rowdot(const float* h, const float* w, long long w_group_stride, const float* b,
+                           long long b_group_stride, float* q, int R, int N, int rows_per_group, void* stream) {
   SERL_CHECK_ARG(h && w && b && q && R >= 1 && N >= 1 && rows_per_group >= 1, "rowdot: bad args");
-  hipLaunchKernelGGL(rowdot_kernel, dim3(cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, h, w, b, q, R, N,
-                     rows_per_group);
+  hipLaunchKernelGGL(rowdot_kernel, dim3(cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, h, w, w_group_stride, b,
+                     b_group_stride, q, R, N, rows_per_group);
   SERL_CHECK_LAUNCH("rowdot");
   return SERL_OK;
 }

@@ -1,0 +1,299 @@
+"""Device-side forward / backward of the networks on the learner path, as sequences of HIP
+kernel launches (serl_amd.ops) over flat parameter stores and a per-batch-size workspace.
+
+What is mirrored (paths relative to the reference):
+  encoder   TwoD4PGEncoder + SpatialLearnedEmbeddings   serl/networks/encoders/two_d4pg_encoder.py, spatial.py
+  trunk     PixelMultiplexer Dense(512)/LN/tanh + state Dense(latent)/LN/tanh   serl/networks/pixel_multiplexer.py:25-45
+  ensemble  Ensemble(StateActionValue(MLP[, LayerNorm]))  serl/networks/{ensemble,state_action_value,mlp}.py
+  policy    TanhNormal(MLP)                                serl/distributions/tanh_normal.py
+Backward passes are hand-derived; tests check them against torch autograd on the CPU oracle.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .. import ops
+from .spec import NetConfig, SLE_FEATURES, TRUNK_DIM, actor_head_prefix, critic_head_prefix
+
+RELU, TANH = ops.ACT_RELU, ops.ACT_TANH
+
+
+class Workspace:
+    """Named, lazily allocated device buffers (activations, gradients of activations, split-K slabs)."""
+
+    def __init__(self, device):
+        self.device = device
+        self._t = {}
+
+    def tensor(self, name, shape, dtype=torch.float32):
+        t = self._t.get(name)
+        shape = tuple(int(s) for s in shape)
+        if t is None or tuple(t.shape) != shape or t.dtype != dtype:
+            t = torch.zeros(shape, dtype=dtype, device=self.device)
+            self._t[name] = t
+        return t
+
+    def ptr(self, name, shape, dtype=torch.float32) -> int:
+        return self.tensor(name, shape, dtype).data_ptr()
+
+    def nbytes(self):
+        return sum(t.numel() * t.element_size() for t in self._t.values())
+
+
+def _ksplit(K):
+    """Split-K factor for the skinny (M = batch) trunk GEMM so that >= ~256 blocks are in flight."""
+    if K < 1024:
+        return 1
+    n = 16
+    while n > 1 and (K + n - 1) // n < 64:
+        n //= 2
+    klen = ((K + n - 1) // n + 15) // 16 * 16
+    return (K + klen - 1) // klen
+
+
+# =============================================================================== encoder
+def encoder_fwd(cfg: NetConfig, passes, B, ws: Workspace, st):
+    """passes: list of (tag, ParamStore, [u8 image ptr per camera in cfg.cams order]).
+    All passes x cameras run as groups of one launch per conv layer. Writes ws['enc_<tag>'] (B, enc_dim)."""
+    layers = cfg.conv_layers()
+    nl, ncam = len(layers), len(cfg.cams)
+    groups = [(tag, store, ci, imgs[ci]) for tag, store, imgs in passes for ci in range(ncam)]
+    for g0 in range(0, len(groups), 8):
+        chunk = groups[g0:g0 + 8]
+        xs = [g[3] for g in chunk]
+        for li, L in enumerate(layers):
+            wsp = [g[1].ptr("image_encoder", f"Conv_{g[2] * nl + li}", "kernel") for g in chunk]
+            bsp = [g[1].ptr("image_encoder", f"Conv_{g[2] * nl + li}", "bias") for g in chunk]
+            ys = [ws.ptr(f"act{li}_{g[0]}_{g[2]}", (B, L.OH, L.OW, L.F)) for g in chunk]
+            ops.conv2d_fwd(xs, wsp, bsp, ys, li == 0, B, L.IH, L.IW, L.C, L.K, L.K, L.S, L.F, True, st)
+            xs = ys
+    last = layers[-1]
+    for tag, store, ci, _ in groups:
+        enc = ws.ptr(f"enc_{tag}", (B, cfg.enc_dim))
+        feat = ws.ptr(f"act{nl - 1}_{tag}_{ci}", (B, last.OH, last.OW, last.F))
+        ops.sle_fwd(feat, store.ptr("image_encoder", f"SpatialLearnedEmbeddings_{ci}", "kernel"),
+                    enc + 4 * ci * last.F * SLE_FEATURES, cfg.enc_dim, B, last.OH * last.OW, last.F, SLE_FEATURES, st)
+
+
+def encoder_bwd(cfg: NetConfig, tag, store, grads, imgs, B, ws: Workspace, st):
+    """Backward of one encoder pass from ws['denc_<tag>'] (B, enc_dim) into `grads` (same layout as store)."""
+    layers = cfg.conv_layers()
+    nl, ncam = len(layers), len(cfg.cams)
+    last = layers[-1]
+    denc = ws.ptr(f"denc_{tag}", (B, cfg.enc_dim))
+    for ci in range(ncam):
+        feat = ws.ptr(f"act{nl - 1}_{tag}_{ci}", (B, last.OH, last.OW, last.F))
+        dfeat = ws.ptr(f"dact{nl - 1}_{ci}", (B, last.OH, last.OW, last.F))
+        ops.sle_bwd(denc + 4 * ci * last.F * SLE_FEATURES, cfg.enc_dim,
+                    store.ptr("image_encoder", f"SpatialLearnedEmbeddings_{ci}", "kernel"), feat, dfeat,
+                    grads.ptr("image_encoder", f"SpatialLearnedEmbeddings_{ci}", "kernel"),
+                    B, last.OH * last.OW, last.F, SLE_FEATURES, st)
+    slab_bytes = max(ops.conv2d_wgrad_workspace_bytes(ncam, B, L.IH, L.IW, L.C, L.K, L.K, L.S, L.F) for L in layers)
+    slab = ws.ptr("wgrad_slab", (slab_bytes // 4,))
+    for li in range(nl - 1, -1, -1):
+        L = layers[li]
+        dz = [ws.ptr(f"dact{li}_{ci}", (B, L.OH, L.OW, L.F)) for ci in range(ncam)]
+        if li == 0:
+            xs = list(imgs)
+        else:
+            P = layers[li - 1]
+            xs = [ws.ptr(f"act{li - 1}_{tag}_{ci}", (B, P.OH, P.OW, P.F)) for ci in range(ncam)]
+        ops.conv2d_wgrad(xs, dz,
+                         [grads.ptr("image_encoder", f"Conv_{ci * nl + li}", "kernel") for ci in range(ncam)],
+                         [grads.ptr("image_encoder", f"Conv_{ci * nl + li}", "bias") for ci in range(ncam)],
+                         slab, slab_bytes, li == 0, B, L.IH, L.IW, L.C, L.K, L.K, L.S, L.F, st)
+        if li > 0:
+            P = layers[li - 1]
+            dx = [ws.ptr(f"dact{li - 1}_{ci}", (B, P.OH, P.OW, P.F)) for ci in range(ncam)]
+            ops.conv2d_dgrad(dz, [store.ptr("image_encoder", f"Conv_{ci * nl + li}", "kernel") for ci in range(ncam)],
+                             xs, dx, B, L.IH, L.IW, L.C, L.K, L.K, L.S, L.F, st)
+
+
+# =============================================================================== trunk
+def trunk_fwd(cfg: NetConfig, tag, store, state_ptr, z_ptr, ldz, B, ws: Workspace, st, save):
+    """z[:, :512] = tanh(LN(Dense_0(enc))), z[:, 512:512+latent] = tanh(LN(Dense_1(state)))."""
+    K = cfg.enc_dim
+    ns = _ksplit(K)
+    slab = ws.ptr(f"slab0_{tag}", (ns, B, TRUNK_DIM))
+    ops.gemm(ws.ptr(f"enc_{tag}", (B, K)), store.ptr("Dense_0", "kernel"), slab, None, 1, B, TRUNK_DIM, K,
+             a_ms=K, a_ks=1, b_ks=TRUNK_DIM, b_ns=1, c_ms=TRUNK_DIM, nsplit=ns, c_split_stride=B * TRUNK_DIM, stream=st)
+    ops.ln_act_fwd(slab, ns, B * TRUNK_DIM, TRUNK_DIM, store.ptr("Dense_0", "bias"), store.ptr("LayerNorm_0", "scale"),
+                   store.ptr("LayerNorm_0", "bias"), 0, z_ptr, ldz,
+                   ws.ptr(f"xhat0_{tag}", (B, TRUNK_DIM)) if save else None,
+                   ws.ptr(f"rstd0_{tag}", (B,)) if save else None, B, TRUNK_DIM, B, True, TANH, st)
+    Ld, Sd = cfg.latent_dim, cfg.state_dim
+    pre1 = ws.ptr(f"pre1_{tag}", (B, Ld))
+    ops.gemm(state_ptr, store.ptr("Dense_1", "kernel"), pre1, None, 1, B, Ld, Sd, a_ms=Sd, a_ks=1, b_ks=Ld, b_ns=1,
+             c_ms=Ld, stream=st)
+    ops.ln_act_fwd(pre1, 1, 0, Ld, store.ptr("Dense_1", "bias"), store.ptr("LayerNorm_1", "scale"),
+                   store.ptr("LayerNorm_1", "bias"), 0, z_ptr + 4 * TRUNK_DIM, ldz,
+                   ws.ptr(f"xhat1_{tag}", (B, Ld)) if save else None, ws.ptr(f"rstd1_{tag}", (B,)) if save else None,
+                   B, Ld, B, True, TANH, st)
+
+
+def trunk_bwd(cfg: NetConfig, tag, store, grads, state_ptr, z_ptr, ldz, dz_ptr, lddz, B, ws: Workspace, st, need_denc):
+    K, Ld, Sd = cfg.enc_dim, cfg.latent_dim, cfg.state_dim
+    dpre0 = ws.ptr("dpre0", (B, TRUNK_DIM)); g0 = ws.ptr("g0", (B, TRUNK_DIM))
+    xh0 = ws.ptr(f"xhat0_{tag}", (B, TRUNK_DIM))
+    ops.ln_act_bwd(dz_ptr, lddz, None, None, 0, z_ptr, ldz, xh0, ws.ptr(f"rstd0_{tag}", (B,)),
+                   store.ptr("LayerNorm_0", "scale"), 0, dpre0, g0, B, TRUNK_DIM, B, True, TANH, st)
+    ops.colsum(g0, grads.ptr("LayerNorm_0", "bias"), 1, B, TRUNK_DIM, TRUNK_DIM, 0, st,
+               x1=dpre0, out1=grads.ptr("Dense_0", "bias"), x2=g0, mul2=xh0, out2=grads.ptr("LayerNorm_0", "scale"))
+    enc = ws.ptr(f"enc_{tag}", (B, K))
+    ops.gemm(enc, dpre0, grads.ptr("Dense_0", "kernel"), None, 1, K, TRUNK_DIM, B, a_ms=1, a_ks=K,
+             b_ks=TRUNK_DIM, b_ns=1, c_ms=TRUNK_DIM, a_kcontig=False, stream=st)
+    if need_denc:
+        ops.gemm(dpre0, store.ptr("Dense_0", "kernel"), ws.ptr(f"denc_{tag}", (B, K)), None, 1, B, K, TRUNK_DIM,
+                 a_ms=TRUNK_DIM, a_ks=1, b_ks=1, b_ns=TRUNK_DIM, c_ms=K, b_ncontig=False, stream=st)
+    dpre1 = ws.ptr("dpre1", (B, Ld)); g1 = ws.ptr("g1", (B, Ld))
+    xh1 = ws.ptr(f"xhat1_{tag}", (B, Ld))
+    ops.ln_act_bwd(dz_ptr + 4 * TRUNK_DIM, lddz, None, None, 0, z_ptr + 4 * TRUNK_DIM, ldz, xh1,
+                   ws.ptr(f"rstd1_{tag}", (B,)), store.ptr("LayerNorm_1", "scale"), 0, dpre1, g1, B, Ld, B, True, TANH, st)
+    ops.colsum(g1, grads.ptr("LayerNorm_1", "bias"), 1, B, Ld, Ld, 0, st,
+               x1=dpre1, out1=grads.ptr("Dense_1", "bias"), x2=g1, mul2=xh1, out2=grads.ptr("LayerNorm_1", "scale"))
+    ops.gemm(state_ptr, dpre1, grads.ptr("Dense_1", "kernel"), None, 1, Sd, Ld, B, a_ms=1, a_ks=Sd, b_ks=Ld, b_ns=1,
+             c_ms=Ld, a_kcontig=False, stream=st)
+
+
+# =============================================================================== critic ensemble
+def ensemble_fwd(cfg: NetConfig, tag, store, m0, mstride, E, inp_ptr, ld_inp, B, ws: Workspace, st, save):
+    """Members m0, m0+mstride, ... (E of them) of the critic ensemble on a shared input (B, ld_inp).
+    Returns ptr of q (E, B)."""
+    pre = critic_head_prefix(cfg)
+    din = cfg.latent + cfg.action_dim
+    ln = cfg.critic_layer_norm
+    a_ptr, a_zs, a_ms = inp_ptr, 0, ld_inp
+    for i, h in enumerate(cfg.hidden_dims):
+        W = store.ptr(*pre, "MLP_0", f"Dense_{i}", "kernel") + 4 * m0 * din * h
+        bias = store.ptr(*pre, "MLP_0", f"Dense_{i}", "bias") + 4 * m0 * h
+        hbuf = ws.ptr(f"h{i}_{tag}", (E, B, h))
+        if ln:
+            pbuf = ws.ptr(f"epre{i}", (E, B, h))
+            ops.gemm(a_ptr, W, pbuf, None, E, B, h, din, a_zs=a_zs, a_ms=a_ms, a_ks=1, b_zs=mstride * din * h,
+                     b_ks=h, b_ns=1, c_zs=B * h, c_ms=h, stream=st)
+            ops.ln_act_fwd(pbuf, 1, 0, h, bias, store.ptr(*pre, "MLP_0", f"LayerNorm_{i}", "scale") + 4 * m0 * h,
+                           store.ptr(*pre, "MLP_0", f"LayerNorm_{i}", "bias") + 4 * m0 * h, mstride * h, hbuf, h,
+                           ws.ptr(f"exh{i}_{tag}", (E, B, h)) if save else None,
+                           ws.ptr(f"ers{i}_{tag}", (E * B,)) if save else None, E * B, h, B, True, RELU, st)
+        else:
+            ops.gemm(a_ptr, W, hbuf, bias, E, B, h, din, a_zs=a_zs, a_ms=a_ms, a_ks=1, b_zs=mstride * din * h,
+                     b_ks=h, b_ns=1, c_zs=B * h, c_ms=h, bias_zs=mstride * h, relu=True, stream=st)
+        a_ptr, a_zs, a_ms, din = hbuf, B * h, h, h
+    q = ws.ptr(f"q_{tag}", (E, B))
+    ops.rowdot(a_ptr, store.ptr(*pre, "Dense_0", "kernel") + 4 * m0 * din, mstride * din,
+               store.ptr(*pre, "Dense_0", "bias") + 4 * m0, mstride, q, E * B, din, B, st)
+    return q
+
+
+def ensemble_bwd(cfg: NetConfig, tag, store, grads, dq_ptr, inp_ptr, ld_inp, B, ws: Workspace, st):
+    """Backward of the full ensemble from dq (E, B). Writes parameter grads when `grads` is given and
+    returns ptr of dinp (B, latent+action) = sum over members."""
+    pre = critic_head_prefix(cfg)
+    E, ln = cfg.num_qs, cfg.critic_layer_norm
+    dims = [cfg.latent + cfg.action_dim] + list(cfg.hidden_dims)
+    nl = len(cfg.hidden_dims)
+    hl = dims[-1]
+    if grads is not None:
+        ops.colsum(ws.ptr(f"h{nl - 1}_{tag}", (E, B, hl)), grads.ptr(*pre, "Dense_0", "kernel"), E, B, hl, hl, hl, st,
+                   w=dq_ptr)
+        ops.colsum(dq_ptr, grads.ptr(*pre, "Dense_0", "bias"), E, B, 1, 1, 1, st)
+    dy_ptr = None
+    for i in range(nl - 1, -1, -1):
+        h, hp = dims[i + 1], dims[i]
+        hbuf = ws.ptr(f"h{i}_{tag}", (E, B, h))
+        dz = ws.ptr(f"edz{i}", (E, B, h))
+        g = ws.ptr(f"eg{i}", (E, B, h)) if ln else None
+        xh = ws.ptr(f"exh{i}_{tag}", (E, B, h)) if ln else None
+        rs = ws.ptr(f"ers{i}_{tag}", (E * B,)) if ln else None
+        gam = store.ptr(*pre, "MLP_0", f"LayerNorm_{i}", "scale") if ln else None
+        if i == nl - 1:
+            ops.ln_act_bwd(None, 0, dq_ptr, store.ptr(*pre, "Dense_0", "kernel"), h, hbuf, h, xh, rs, gam, h, dz, g,
+                           E * B, h, B, ln, RELU, st)
+        else:
+            ops.ln_act_bwd(dy_ptr, h, None, None, 0, hbuf, h, xh, rs, gam, h, dz, g, E * B, h, B, ln, RELU, st)
+        W = store.ptr(*pre, "MLP_0", f"Dense_{i}", "kernel")
+        if grads is not None:
+            gb = grads.ptr(*pre, "MLP_0", f"Dense_{i}", "bias")
+            if ln:
+                ops.colsum(g, grads.ptr(*pre, "MLP_0", f"LayerNorm_{i}", "bias"), E, B, h, h, h, st, x1=dz, out1=gb,
+                           x2=g, mul2=xh, out2=grads.ptr(*pre, "MLP_0", f"LayerNorm_{i}", "scale"))
+            else:
+                ops.colsum(dz, gb, E, B, h, h, h, st)
+            if i == 0:
+                a_ptr, a_zs, a_ks = inp_ptr, 0, ld_inp
+            else:
+                a_ptr, a_zs, a_ks = ws.ptr(f"h{i - 1}_{tag}", (E, B, hp)), B * hp, hp
+            ops.gemm(a_ptr, dz, grads.ptr(*pre, "MLP_0", f"Dense_{i}", "kernel"), None, E, hp, h, B, a_zs=a_zs, a_ms=1,
+                     a_ks=a_ks, b_zs=B * h, b_ks=h, b_ns=1, c_zs=hp * h, c_ms=h, a_kcontig=False, stream=st)
+        if i > 0:
+            dy_ptr = ws.ptr(f"edh{i - 1}", (E, B, hp))
+            ops.gemm(dz, W, dy_ptr, None, E, B, hp, h, a_zs=B * h, a_ms=h, a_ks=1, b_zs=hp * h, b_ks=1, b_ns=h,
+                     c_zs=B * hp, c_ms=hp, b_ncontig=False, stream=st)
+        else:
+            dinp = ws.ptr("dinp", (B, hp))
+            ops.gemm(dz, W, dinp, None, 1, B, hp, E * h, seglen=h, a_ss=B * h, a_ms=h, a_ks=1, b_ss=hp * h, b_ks=1,
+                     b_ns=h, c_ms=hp, b_ncontig=False, stream=st)
+            return dinp
+
+
+# =============================================================================== policy head
+def policy_fwd(cfg: NetConfig, tag, store, z_ptr, ldz, B, ws: Workspace, st, key, row_offset, total_rows,
+               act_ptr, ld_act, deterministic=False, save=False, want_logp=True):
+    """TanhNormal(MLP) on z (B, latent): writes actions to act_ptr (row stride ld_act); returns ptr of logp (B,)."""
+    pre = actor_head_prefix(cfg)
+    A = cfg.action_dim
+    a_ptr, a_ms, din = z_ptr, ldz, cfg.latent
+    for i, h in enumerate(cfg.hidden_dims):
+        hbuf = ws.ptr(f"ph{i}_{tag}", (B, h))
+        ops.gemm(a_ptr, store.ptr(*pre, "MLP_0", f"Dense_{i}", "kernel"), hbuf,
+                 store.ptr(*pre, "MLP_0", f"Dense_{i}", "bias"), 1, B, h, din, a_ms=a_ms, a_ks=1, b_ks=h, b_ns=1,
+                 c_ms=h, relu=True, stream=st)
+        a_ptr, a_ms, din = hbuf, h, h
+    ms = ws.ptr(f"ms_{tag}", (B, 2 * A))
+    wm, wl = store.ptr(*pre, "OutputDenseMean", "kernel"), store.ptr(*pre, "OutputDenseLogStd", "kernel")
+    bm, bl = store.ptr(*pre, "OutputDenseMean", "bias"), store.ptr(*pre, "OutputDenseLogStd", "bias")
+    ops.gemm(a_ptr, wm, ms, bm, 2, B, A, din, a_zs=0, a_ms=a_ms, a_ks=1, b_zs=(wl - wm) // 4, b_ks=A, b_ns=1,
+             c_zs=A, c_ms=2 * A, bias_zs=(bl - bm) // 4, stream=st)
+    logp = ws.ptr(f"logp_{tag}", (B,)) if want_logp else None
+    ops.tanh_gaussian_fwd(ms, ms + 4 * A, 2 * A, act_ptr, ld_act, None,
+                          ws.ptr(f"eps_{tag}", (B, A)) if save else None, logp, B, A,
+                          key if key is not None else (0, 0), row_offset, total_rows, deterministic, st)
+    return logp
+
+
+def policy_bwd(cfg: NetConfig, tag, store, grads, z_ptr, ldz, B, ws: Workspace, st, need_dz):
+    """Backward from ws['dms'] (B, 2A) = [dmean | dlogstd]; returns ptr of dz (B, latent) when need_dz."""
+    pre = actor_head_prefix(cfg)
+    A = cfg.action_dim
+    nl = len(cfg.hidden_dims)
+    dims = [cfg.latent] + list(cfg.hidden_dims)
+    hl = dims[-1]
+    dms = ws.ptr("dms", (B, 2 * A))
+    wm, wl = store.ptr(*pre, "OutputDenseMean", "kernel"), store.ptr(*pre, "OutputDenseLogStd", "kernel")
+    gwm, gwl = grads.ptr(*pre, "OutputDenseMean", "kernel"), grads.ptr(*pre, "OutputDenseLogStd", "kernel")
+    hlast = ws.ptr(f"ph{nl - 1}_{tag}", (B, hl))
+    ops.gemm(hlast, dms, gwm, None, 2, hl, A, B, a_zs=0, a_ms=1, a_ks=hl, b_zs=A, b_ks=2 * A, b_ns=1,
+             c_zs=(gwl - gwm) // 4, c_ms=A, a_kcontig=False, stream=st)
+    ops.colsum(dms, grads.ptr(*pre, "OutputDenseMean", "bias"), 1, B, A, 2 * A, 0, st)
+    ops.colsum(dms + 4 * A, grads.ptr(*pre, "OutputDenseLogStd", "bias"), 1, B, A, 2 * A, 0, st)
+    dh = ws.ptr(f"pdh{nl - 1}", (B, hl))
+    ops.gemm(dms, wm, dh, None, 1, B, hl, 2 * A, seglen=A, a_ss=A, a_ms=2 * A, a_ks=1, b_ss=(wl - wm) // 4, b_ks=1,
+             b_ns=A, c_ms=hl, b_ncontig=False, stream=st)
+    for i in range(nl - 1, -1, -1):
+        h, hp = dims[i + 1], dims[i]
+        hbuf = ws.ptr(f"ph{i}_{tag}", (B, h))
+        dz = ws.ptr(f"pdz{i}", (B, h))
+        ops.ln_act_bwd(dh, h, None, None, 0, hbuf, h, None, None, None, 0, dz, None, B, h, B, False, RELU, st)
+        ops.colsum(dz, grads.ptr(*pre, "MLP_0", f"Dense_{i}", "bias"), 1, B, h, h, 0, st)
+        if i == 0:
+            a_ptr, a_ks = z_ptr, ldz
+        else:
+            a_ptr, a_ks = ws.ptr(f"ph{i - 1}_{tag}", (B, hp)), hp
+        ops.gemm(a_ptr, dz, grads.ptr(*pre, "MLP_0", f"Dense_{i}", "kernel"), None, 1, hp, h, B, a_ms=1, a_ks=a_ks,
+                 b_ks=h, b_ns=1, c_ms=h, a_kcontig=False, stream=st)
+        if i > 0 or need_dz:
+            dh = ws.ptr(f"pdh{i - 1}" if i > 0 else "pdzlat", (B, hp))
+            ops.gemm(dz, store.ptr(*pre, "MLP_0", f"Dense_{i}", "kernel"), dh, None, 1, B, hp, h, a_ms=h, a_ks=1,
+                     b_ks=1, b_ns=h, c_ms=hp, b_ncontig=False, stream=st)
+    return dh if need_dz else None

@@ -65,8 +65,8 @@ def colsum(x0, out0, ngroups, rows_per_group, N, ldx, out_gs, stream, w=None, mu
     call("serl_colsum", x0, w, mul, out0, x1, out1, x2, mul2, out2, ngroups, rows_per_group, N, ldx, out_gs, stream)
 
 
-def rowdot(h, w, b, q, R, N, rows_per_group, stream):
-    call("serl_rowdot", h, w, b, q, R, N, rows_per_group, stream)
+def rowdot(h, w, w_gs, b, b_gs, q, R, N, rows_per_group, stream):
+    call("serl_rowdot", h, w, w_gs, b, b_gs, q, R, N, rows_per_group, stream)
 
 
 def copy2d(dst, ldd, src, lds, rows, cols, stream):
@@ -116,12 +116,12 @@ def sle_bwd(dout, ldo, ker, feat, dfeat, dker, B, HW, C, F, stream):
     call("serl_sle_bwd", dout, ldo, ker, feat, dfeat, dker, B, HW, C, F, stream)
 
 
-def gather_crop_frames(frames, cap, indx, off_obs, off_next, out_obs, out_next, n, H, W, S, pad, stream):
-    call("serl_gather_crop_frames", frames, cap, indx, off_obs, off_next, out_obs, out_next, n, H, W, S, pad, stream)
+def gather_crop_frames(frames, cap, indx, T, t0, off, out, n, H, W, S, pad, stream):
+    call("serl_gather_crop_frames", frames, cap, indx, T, t0, off, out, n, H, W, S, pad, stream)
 
 
-def gather_crop_packed(packed, off_obs, off_next, out_obs, out_next, n, H, W, S, pad, stream):
-    call("serl_gather_crop_packed", packed, off_obs, off_next, out_obs, out_next, n, H, W, S, pad, stream)
+def gather_crop_packed(src, T, t0, off, out, n, H, W, S, pad, stream):
+    call("serl_gather_crop_packed", src, T, t0, off, out, n, H, W, S, pad, stream)
 
 
 def gather_window(frames, cap, indx, out, n, HW3, S, stream):

@@ -219,7 +219,7 @@ def test_rowdot_and_rank1_bwd(dev):
     w = rng.standard_normal((E, N)).astype(np.float32); b = rng.standard_normal(E).astype(np.float32)
     H, W, Bi = dv(h, dev), dv(w, dev), dv(b, dev)
     Q = torch.zeros(E * B, device=dev)
-    ops.rowdot(H.data_ptr(), W.data_ptr(), Bi.data_ptr(), Q.data_ptr(), E * B, N, B, st)
+    ops.rowdot(H.data_ptr(), W.data_ptr(), N, Bi.data_ptr(), 1, Q.data_ptr(), E * B, N, B, st)
     torch.cuda.synchronize()
     ref = np.einsum("ebn,en->eb", h.reshape(E, B, N).astype(np.float64), w.astype(np.float64)) + b[:, None]
     close(Q.cpu().numpy().reshape(E, B), ref, what="rowdot")
@@ -306,18 +306,24 @@ def test_gather_crop_bit_exact(dev, S):
     ref_nxt = ol.random_crop_batch(win[..., 1:], offs[1])
     Fr, Ix, Of = dv(frames, dev), dv(indx, dev), dv(offs, dev)
     o1 = torch.zeros((n, H, W, 3 * S), dtype=torch.uint8, device=dev); o2 = torch.zeros_like(o1)
-    ops.gather_crop_frames(Fr.data_ptr(), cap, Ix.data_ptr(), Of[0].data_ptr(), Of[1].data_ptr(), o1.data_ptr(),
-                           o2.data_ptr(), n, H, W, S, 4, st)
+    ops.gather_crop_frames(Fr.data_ptr(), cap, Ix.data_ptr(), S + 1, 0, Of[0].data_ptr(), o1.data_ptr(), n, H, W, S, 4, st)
+    ops.gather_crop_frames(Fr.data_ptr(), cap, Ix.data_ptr(), S + 1, 1, Of[1].data_ptr(), o2.data_ptr(), n, H, W, S, 4, st)
     torch.cuda.synchronize()
     assert np.array_equal(o1.cpu().numpy().reshape(n, H, W, 3, S), ref_obs)
     assert np.array_equal(o2.cpu().numpy().reshape(n, H, W, 3, S), ref_nxt)
-    # packed source
+    # packed source (S+1 interleaved frames)
     Pk = dv(np.ascontiguousarray(win), dev)
     o1.zero_(); o2.zero_()
-    ops.gather_crop_packed(Pk.data_ptr(), Of[0].data_ptr(), Of[1].data_ptr(), o1.data_ptr(), o2.data_ptr(), n, H, W, S,
-                           4, st)
+    ops.gather_crop_packed(Pk.data_ptr(), S + 1, 0, Of[0].data_ptr(), o1.data_ptr(), n, H, W, S, 4, st)
+    ops.gather_crop_packed(Pk.data_ptr(), S + 1, 1, Of[1].data_ptr(), o2.data_ptr(), n, H, W, S, 4, st)
     torch.cuda.synchronize()
     assert np.array_equal(o1.cpu().numpy().reshape(n, H, W, 3, S), ref_obs)
+    assert np.array_equal(o2.cpu().numpy().reshape(n, H, W, 3, S), ref_nxt)
+    # unpacked source (already split obs / next_obs, T = S)
+    Un = dv(np.ascontiguousarray(win[..., 1:]), dev)
+    o2.zero_()
+    ops.gather_crop_packed(Un.data_ptr(), S, 0, Of[1].data_ptr(), o2.data_ptr(), n, H, W, S, 4, st)
+    torch.cuda.synchronize()
     assert np.array_equal(o2.cpu().numpy().reshape(n, H, W, 3, S), ref_nxt)
     # plain window gather
     wout = torch.zeros((n, H, W, 3, S + 1), dtype=torch.uint8, device=dev)

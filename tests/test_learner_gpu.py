@@ -1,0 +1,146 @@
+"""End-to-end GPU parity: N `update()` calls of the HIP learners vs the CPU oracle from identical
+parameters, batches and RNG.
+
+Stated tolerances (float path): losses / Q / entropy / temperature rel 1e-3 after N updates
+(north_star), per-leaf gradients 2e-4 of the leaf's max magnitude, augmentation and indices bit-exact.
+Parameters after Adam are compared loosely (Adam's first steps are ~sign(g): a gradient that is noise
+around 0 may move a weight by +-lr in either implementation)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import (agent_to_oracle, assert_info_close, assert_tree_close, make_pixel_batch, make_state_batch,
+                     pixel_spaces, state_spaces)
+
+pytestmark = pytest.mark.gpu
+
+
+def _check_params(agent, ostate, lr, steps):
+    for name in ("actor", "critic", "target_critic"):
+        got = getattr(agent, name).store.numpy_tree()
+        ref = ostate[name]["params"]
+        assert_tree_close(got, ref, atol=2.5 * lr * steps, mean_atol=2e-5, what=f"{name} params")
+
+
+@pytest.mark.parametrize("cfgname", ["sac_c1", "rlpd_c2", "redq_m3"])
+def test_state_learner_matches_oracle(dev, cfgname):
+    from oracle import learner as ol
+    from serl_amd.agents import SACLearner
+    obs_space, act_space = state_spaces(17, 6)
+    if cfgname == "sac_c1":       # BASELINE config 1
+        kw = dict(num_qs=2, critic_layer_norm=False, backup_entropy=True, init_temperature=1.0)
+        B, U = 256, 1
+    elif cfgname == "rlpd_c2":    # BASELINE config 2 (UTD shortened for the CPU oracle)
+        kw = dict(num_qs=10, num_min_qs=2, critic_layer_norm=True, backup_entropy=False, init_temperature=0.1)
+        B, U = 256, 4
+    else:                          # general subsample path (non-arithmetic index sets)
+        kw = dict(num_qs=6, num_min_qs=3, critic_layer_norm=True, backup_entropy=True, init_temperature=0.5)
+        B, U = 64, 3
+    agent = SACLearner.create(42, obs_space, act_space, **kw)
+    ostate, ocfg = agent_to_oracle(agent)
+    rng = np.random.default_rng(0)
+    for it in range(3):
+        batch = make_state_batch(rng, B * U, 17, 6)
+        collect = []
+        ostate, oinfo = ol.sac_update(ostate, ocfg, batch, U, collect=collect)
+        agent, info = agent.update(batch, U)
+        assert_info_close(info, oinfo, rtol=1e-3)
+        assert np.array_equal(agent.rng, ostate["rng"])
+        assert_tree_close(agent._shared["critic_grads"].numpy_tree(), collect[-2]["grads"], rtol=2e-4, what="critic grads")
+        assert_tree_close(agent._shared["actor_grads"].numpy_tree(), collect[-1]["grads"], rtol=2e-4, what="actor grads")
+    _check_params(agent, ostate, 3e-4, 3 * U)
+    # acting
+    ob = rng.standard_normal(17).astype(np.float32)
+    a, agent2 = agent.sample_actions(ob)
+    oa, ostate2 = ol.sample_actions(ostate, ocfg, ob)
+    assert np.allclose(a, oa, atol=2e-4) and np.array_equal(agent2.rng, ostate2["rng"])
+    assert np.allclose(agent.eval_actions(ob), ol.eval_actions(ostate, ocfg, ob), atol=2e-4)
+    # immutability: the old agent still acts with its old parameters
+    assert np.array_equal(agent.rng, ostate["rng"])
+
+
+@pytest.mark.parametrize("variant", ["e1_packed", "e0_unpacked_small"])
+def test_drq_learner_matches_oracle(dev, variant):
+    from oracle import learner as ol
+    from serl_amd.agents import DrQLearner
+    if variant == "e1_packed":     # BASELINE config 3 shapes, RLPD settings, tiny batch for the CPU oracle
+        H = W = 128; S = 3; B, U = 8, 2
+        kw = dict(cnn_features=(32, 64, 128, 256), cnn_filters=(3, 3, 3, 3), cnn_strides=(2, 2, 2, 2), latent_dim=64,
+                  num_qs=10, num_min_qs=2, critic_layer_norm=True, backup_entropy=False, init_temperature=0.1)
+        packed = True
+    else:                           # DrQLearner defaults (stride 2,1,1,1), stack 1, unpacked batch
+        H = W = 32; S = 1; B, U = 6, 1
+        kw = dict(num_qs=2, critic_layer_norm=False, backup_entropy=True)
+        packed = False
+    keys = ("wrist_1", "wrist_2")
+    obs_space, act_space = pixel_spaces(keys, H, W, S, 19, 7)
+    agent = DrQLearner.create(42, obs_space, act_space, pixel_keys=keys, **kw)
+    ostate, ocfg = agent_to_oracle(agent)
+    rng = np.random.default_rng(1)
+    for it in range(2):
+        batch = make_pixel_batch(rng, B * U, keys, H, W, S, 19, 7, packed=packed)
+        collect = []
+        ostate, oinfo = ol.drq_update(ostate, ocfg, batch, U, collect=collect)
+        agent, info = agent.update(batch, U, pixel_keys=keys)
+        # augmentation bit-exact (uint8)
+        ws = agent._ws(B)
+        for side, okey in (("obs", "observations"), ("next", "next_observations")):
+            for cam in keys:
+                got = ws.tensor(f"aug_{side}_{cam}", (B * U, H, W, 3 * S), torch.uint8).cpu().numpy()
+                assert np.array_equal(got.reshape(B * U, H, W, 3, S), collect[0][okey][cam]), f"aug {side} {cam}"
+        assert_info_close(info, oinfo, rtol=1e-3)
+        assert np.array_equal(agent.rng, ostate["rng"])
+        assert_tree_close(agent._shared["critic_grads"].numpy_tree(), collect[-2]["grads"], rtol=2e-4, what="critic grads")
+        assert_tree_close(agent._shared["actor_grads"].numpy_tree(), collect[-1]["grads"], rtol=2e-4, what="actor grads")
+    _check_params(agent, ostate, 3e-4, 2 * U)
+    ob = {k: rng.integers(0, 256, size=(H, W, 3, S), dtype=np.uint8) for k in keys}
+    ob["state"] = rng.standard_normal(19).astype(np.float32)
+    a, agent2 = agent.sample_actions(ob)
+    oa, _ = ol.sample_actions(ostate, ocfg, ob)
+    assert np.allclose(a, oa, atol=5e-4)
+    assert np.allclose(agent.eval_actions(ob), ol.eval_actions(ostate, ocfg, ob), atol=5e-4)
+
+
+def test_device_replay_feeds_update(dev):
+    """MemoryEfficientReplayBuffer(device=cuda) iterator -> lazy FrameWindows -> fused gather+crop in update():
+    same result as the host buffer + packed numpy batch (and both equal the oracle's sampled windows)."""
+    from oracle import replay as orp
+    from serl_amd.agents import DrQLearner
+    from serl_amd.data import MemoryEfficientReplayBuffer
+    keys = ("wrist_1", "wrist_2")
+    H = W = 32; S = 3
+    obs_space, act_space = pixel_spaces(keys, H, W, S, 19, 7)
+    bufs = [MemoryEfficientReplayBuffer(obs_space, act_space, 200, pixel_keys=keys, device=d) for d in (None, "cuda")]
+    spec = {k: ((H, W, 3, S), np.uint8) for k in keys}
+    spec["state"] = ((19,), np.float32)
+    obuf = orp.new_frame_buffer(spec, ((7,), np.float32), 200, keys)
+    rng = np.random.default_rng(3)
+    from helpers import rollout_transitions
+    for tr in rollout_transitions(rng, 260, keys, H, W, S, 19, 7, episode_len=23):   # wraps the ring
+        for b in bufs:
+            b.insert(tr)
+        orp.frame_insert(obuf, tr)
+    assert np.array_equal(bufs[0]._is_correct_index, obuf["valid"]) and np.array_equal(bufs[1]._is_correct_index, obuf["valid"])
+    for b in bufs:
+        b.seed(7)
+    orng = orp.make_rng(7)
+    args = dict(batch_size=24, pack_obs_and_next_obs=True, demo_batch_size=12, demo_size=50)
+    host = bufs[0].sample(**args)
+    dev_np = bufs[1].sample(**args)            # device gather + D2H
+    oidx = orp.frame_sample_indices(obuf, orng, 24, 12, 50)
+    obatch = orp.frame_gather(obuf, oidx, True)
+    for k in keys:
+        assert np.array_equal(host["observations"][k], obatch["observations"][k])
+        assert np.array_equal(dev_np["observations"][k], obatch["observations"][k])
+    assert np.array_equal(host["actions"], obatch["actions"])
+    # lazy iterator batch -> update == packed host batch -> update
+    for b in bufs:
+        b.seed(11)
+    it = bufs[1].get_iterator(sample_args=dict(batch_size=12, pack_obs_and_next_obs=True))
+    lazy = next(it)
+    hostb = bufs[0].sample(batch_size=12, pack_obs_and_next_obs=True)
+    agent = DrQLearner.create(0, obs_space, act_space, pixel_keys=keys, num_qs=2)
+    a1, i1 = agent.update(lazy, 2, pixel_keys=keys)
+    a2, i2 = agent.update(hostb, 2, pixel_keys=keys)
+    assert i1 == i2
+    assert torch.equal(a1.critic.store.flat, a2.critic.store.flat)
