@@ -281,7 +281,7 @@ def update_critic(state, cfg, batch, dtype=torch.float32):
     target = dict(params=polyak(critic["params"], state["target_critic"]["params"], cfg["tau"]))
     new = dict(state)
     new.update(critic=critic, target_critic=target, rng=rng)
-    info = dict(critic_loss=float(loss), q=float(qs.mean()))
+    info = dict(critic_loss=float(loss.detach()), q=float(qs.detach().mean()))
     aux = dict(grads=grads_np, target_q=target_q.numpy(), next_actions=next_a.numpy(),
                qs=qs.detach().numpy(), subsample=indx)
     return new, info, aux
@@ -318,7 +318,7 @@ def update_actor(state, cfg, batch, dtype=torch.float32):
     actor = adam_step(state["actor"], grads_np, cfg["actor_lr"])
     new = dict(state)
     new.update(actor=actor, rng=rng)
-    info = dict(actor_loss=float(loss), entropy=float(-logp.mean()))
+    info = dict(actor_loss=float(loss.detach()), entropy=float(-logp.detach().mean()))
     return new, info, dict(grads=grads_np, actions=a.detach().numpy())
 
 

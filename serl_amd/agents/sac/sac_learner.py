@@ -113,9 +113,9 @@ class SACLearner(Agent):
             return int(idx[0]), d, len(idx), idx
         return None, None, len(idx), idx
 
-    def _gathered_target(self, idx):
-        """General num_min_qs > 2: copy the chosen members into a scratch store (rare path)."""
-        cfg, src = self._cfg, self.target_critic.store
+    def _gathered_target(self, idx, src):
+        """General num_min_qs > 2: copy the chosen members of `src` into a scratch store (rare path)."""
+        cfg = self._cfg
         scratch = self._shared.get("tgt_scratch")
         if scratch is None:
             scratch = self._shared["tgt_scratch"] = src.zeros_like()
@@ -193,7 +193,7 @@ class SACLearner(Agent):
             m0, mstride, emin, idx = self._target_members(key_sub)
             tstore = target.store
             if m0 is None:
-                tstore, m0, mstride = self._gathered_target(idx), 0, 1
+                tstore, m0, mstride = self._gathered_target(idx, target.store), 0, 1
             self._features([("A", actor.store, "next"), ("T", target.store, "next"), ("C", critic.store, "obs")],
                            feats, lo, B, ws, st, save_tag="C")
             nlogp = nn.policy_fwd(cfg, "A", actor.store, zA, ldz, B, ws, st, key_act, rank * B, Bg,
