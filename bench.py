@@ -1,0 +1,172 @@
+"""Headline benchmark: learner grad-steps/sec, DrQ-RLPD 128x128 pixels, batch 256, 10 critics, UTD 20
+(BASELINE.json `metric`; SURVEY.md 8d config C3 with RLPD settings).
+
+One "step" = one `agent.update(batch, utd_ratio=20)` call = 20 critic grad-steps + 1 actor/temperature
+step + the DrQ gather/unpack/crop of the whole 5120-sample batch.  Inputs (replay frame store, sampled
+indices, states, actions) are resident in HBM when the timed region starts.
+`value` = grad-steps/s x (global_batch / 256): at N GPUs every rank keeps batch 256 (weak scaling, one RCCL
+gradient all-reduce per critic step), so value = batch-256-equivalent grad-steps/s of the whole job.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--no-cpu-baseline]
+N > 1 is launched by torch.distributed.run, one rank per GPU.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+KEYS = ("wrist_1", "wrist_2")
+H = W = 128
+STACK, STATE_DIM, ACT_DIM = 3, 19, 7
+BATCH, UTD = 256, 20
+AGENT_KW = dict(cnn_features=(32, 64, 128, 256), cnn_filters=(3, 3, 3, 3), cnn_strides=(2, 2, 2, 2), latent_dim=64,
+                num_qs=10, num_min_qs=2, critic_layer_norm=True, backup_entropy=False, init_temperature=0.1,
+                hidden_dims=(256, 256), discount=0.99, tau=0.005)
+PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+FLOP_PER_GRAD_STEP = 304e9        # 301 critic + 3.1 amortised actor (2 FLOP / MAC)
+
+
+def fill_buffer(buf, n_transitions, seed):
+    from helpers import rollout_transitions
+    rng = np.random.default_rng(seed)
+    for tr in rollout_transitions(rng, n_transitions, KEYS, H, W, STACK, STATE_DIM, ACT_DIM, episode_len=100):
+        buf.insert(tr)
+
+
+def cpu_baseline(seed=0):
+    """CPU restatement (oracle, torch-CPU fp32 -- NOT JAX/XLA) on a bounded sample of the same workload:
+    one update() call with UTD 2 at batch 256 (2 grad-steps + the actor/temperature step)."""
+    import torch
+    from helpers import agent_to_oracle, make_pixel_batch, pixel_spaces
+    from oracle import learner as ol
+    from serl_amd.agents import DrQLearner
+    obs_space, act_space = pixel_spaces(KEYS, H, W, STACK, STATE_DIM, ACT_DIM)
+    agent = DrQLearner.create(seed, obs_space, act_space, pixel_keys=KEYS, **AGENT_KW)
+    ostate, ocfg = agent_to_oracle(agent)
+    u = 2
+    batch = make_pixel_batch(np.random.default_rng(seed), BATCH * u, KEYS, H, W, STACK, STATE_DIM, ACT_DIM, packed=True)
+    t0 = time.perf_counter()
+    ol.drq_update(ostate, ocfg, batch, u)
+    dt = time.perf_counter() - t0
+    return {"value": u / dt, "unit": "grad-steps/s", "cores": int(torch.get_num_threads()), "kind": "port",
+            "sample": f"1 update() call, UTD {u}, batch {BATCH} ({u} grad-steps + actor step), {dt:.1f} s; "
+                      "CPU restatement (torch-CPU fp32), not JAX/XLA"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timer", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from helpers import pixel_spaces
+    from serl_amd import ops
+    from serl_amd.agents import DrQLearner
+    from serl_amd.data import MemoryEfficientReplayBuffer
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as td
+        from serl_amd.dist import DataParallel
+        td.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist = DataParallel()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    obs_space, act_space = pixel_spaces(KEYS, H, W, STACK, STATE_DIM, ACT_DIM)
+    agent = DrQLearner.create(42, obs_space, act_space, pixel_keys=KEYS, dist=dist, **AGENT_KW)
+    # online buffer + demo prefix: 50/50 demo/online mixing via the tail-overwrite rule
+    buf = MemoryEfficientReplayBuffer(obs_space, act_space, 6000, pixel_keys=KEYS, device="cuda")
+    fill_buffer(buf, 4000, seed=rank)
+    buf.seed(rank)
+    sample_args = dict(batch_size=BATCH * UTD, pack_obs_and_next_obs=True, demo_batch_size=BATCH * UTD // 2,
+                       demo_size=1000)
+    it = buf.get_iterator(queue_size=1, sample_args=sample_args)
+    t0 = time.perf_counter()
+    batches = [next(it) for _ in range(args.warmup + args.steps)]
+    sample_ms = (time.perf_counter() - t0) * 1e3 / len(batches)
+
+    def barrier():
+        if dist is not None:
+            import torch.distributed as td
+            td.barrier()
+        torch.cuda.synchronize()
+
+    for b in batches[:args.warmup]:
+        agent, info = agent.update(b, UTD, pixel_keys=KEYS)
+    timer = None
+    if not args.no_kernel_timer:
+        timer = ops.TIMER = ops.KernelTimer()
+    barrier()
+    t0 = time.perf_counter()
+    for b in batches[args.warmup:]:
+        agent, info = agent.update(b, UTD, pixel_keys=KEYS)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ops.TIMER = None
+    if dist is not None:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        import torch.distributed as td
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    grad_steps = args.steps * UTD
+    value = grad_steps * world / elapsed
+    roofline = None
+    if timer is not None:
+        summ = timer.summary()
+        key = max(summ, key=lambda k: summ[k][0] * summ[k][1])       # largest total time
+        n, ms, flops = summ[key]
+        achieved = flops / (ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": f"igemm {key[0]} (u8_in={key[1]}, groups={key[2]}, B={key[3]}, "
+                                               f"IH={key[4]}, C={key[5]}, F={key[6]})",
+                    "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                    "launches_timed": n, "avg_launch_ms": round(ms, 4),
+                    "all_conv_kernels": {f"{k[0]}|u8={k[1]}|g={k[2]}|IH={k[4]}|C={k[5]}|F={k[6]}":
+                                         {"launches": v[0], "avg_ms": round(v[1], 4),
+                                          "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 2)} for k, v in summ.items()}}
+    out = {
+        "metric": "learner grad-steps/sec, DrQ-RLPD 128^2 pixels, batch 256, 10 critics, UTD 20",
+        "value": round(value, 3), "unit": "grad-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "DrQ-RLPD update(): 2 cams 128x128x3 uint8, frame stack 3, conv encoder 32-64-128-256 "
+                               "stride 2, 10 LayerNorm critics / 2 subsampled targets, UTD 20, 50/50 demo tail mixing, "
+                               "HBM-resident MemoryEfficientReplayBuffer",
+                   "batch_per_gpu": BATCH, "global_batch": BATCH * world, "utd": UTD,
+                   "step_definition": "1 step = 1 update() call = 20 critic grad-steps + 1 actor/temperature step",
+                   "value_definition": "grad-steps/s x global_batch/256", "parallelism": f"dp{world}"},
+        "model_tflops": round(value * FLOP_PER_GRAD_STEP / 1e12, 2),
+        "frac_of_fp32_mfma_ceiling": round(value * FLOP_PER_GRAD_STEP / 1e12 / (PEAK_FP32_MFMA_TFLOPS * world), 4),
+        "host_index_sampling_ms_per_update": round(sample_ms, 2),
+        "last_info": {k: round(float(v), 5) for k, v in info.items()},
+    }
+    if roofline is not None:
+        out["roofline"] = roofline
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+        out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        import torch.distributed as td
+        td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

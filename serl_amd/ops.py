@@ -14,16 +14,55 @@ def current_stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+class KernelTimer:
+    """Optional HIP-event bracket around the conv launches (bench.py's live roofline measurement).
+    Events are recorded on torch's current stream, which is the stream the kernels are launched on."""
+
+    def __init__(self):
+        self.records = {}
+
+    def bracket(self, key, flops):
+        import torch
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.records.setdefault(key, []).append((a, b, flops))
+        return a, b
+
+    def summary(self):
+        """key -> (launches, mean ms, flops per launch); call after a device synchronize."""
+        out = {}
+        for key, recs in self.records.items():
+            ms = [a.elapsed_time(b) for a, b, _ in recs]
+            out[key] = (len(ms), sum(ms) / len(ms), recs[0][2])
+        return out
+
+
+TIMER = None   # set to a KernelTimer to enable
+
+
 def conv2d_fwd(xs, ws, bs, ys, in_u8, B, IH, IW, C, KH, KW, stride, F, relu, stream):
     n = len(xs)
     px, kx = ptr_table(xs); pw, kw = ptr_table(ws); pb, kb = ptr_table(bs); py, ky = ptr_table(ys)
+    ev = None
+    if TIMER is not None:
+        OH, OW = (IH - KH) // stride + 1, (IW - KW) // stride + 1
+        ev = TIMER.bracket(("conv2d_fwd", bool(in_u8), n, B, IH, C, F), 2.0 * n * B * OH * OW * F * KH * KW * C)
+        ev[0].record()
     call("serl_conv2d_fwd", n, px, pw, pb, py, int(in_u8), B, IH, IW, C, KH, KW, stride, F, int(relu), stream)
+    if ev is not None:
+        ev[1].record()
 
 
 def conv2d_dgrad(dzs, ws, xacts, dxs, B, IH, IW, C, KH, KW, stride, F, stream):
     n = len(dzs)
     pz, kz = ptr_table(dzs); pw, kw = ptr_table(ws); pa, ka = ptr_table(xacts); pd, kd = ptr_table(dxs)
+    ev = None
+    if TIMER is not None:
+        OH, OW = (IH - KH) // stride + 1, (IW - KW) // stride + 1
+        ev = TIMER.bracket(("conv2d_dgrad", False, n, B, IH, C, F), 2.0 * n * B * OH * OW * F * KH * KW * C)
+        ev[0].record()
     call("serl_conv2d_dgrad", n, pz, pw, pa, pd, B, IH, IW, C, KH, KW, stride, F, stream)
+    if ev is not None:
+        ev[1].record()
 
 
 def conv2d_wgrad_workspace_bytes(ngroups, B, IH, IW, C, KH, KW, stride, F) -> int:
