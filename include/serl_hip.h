@@ -1,0 +1,114 @@
+/* libserl_hip.so -- C ABI of the MI355X (gfx950) kernels behind serl_amd.
+ *
+ * The reference (serl-robot/serl) has no FFI on this path: its learner update is Python that XLA
+ * compiles.  The drop-in boundary therefore is the Python agent/buffer API; this
+ * header is the thin kernel layer underneath it that `serl_amd/_lib.py` binds with ctypes.  Every entry
+ * point cites the reference code whose arithmetic it replaces (paths relative to the reference root).
+ *
+ * Conventions: plain pointers and sizes only; all device pointers are caller-allocated; `stream` is a
+ * hipStream_t; tensors are row-major float32 unless stated; images are NHWC, conv kernels HWIO (flax).
+ * Return value: 0 ok, 1 invalid argument (-> ValueError), 2 HIP error (-> RuntimeError); the message is in
+ * serl_last_error() (thread-local).  No entry point allocates device memory or synchronises.
+ */
+#ifndef SERL_HIP_H
+#define SERL_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* serl_last_error(void);
+int serl_version(void);
+int serl_device_arch(int device, char* out, int out_len);
+
+/* ---- convolution encoder: flax nn.Conv(VALID, bias) + ReLU, serl/networks/encoders/two_d4pg_encoder.py:30-38.
+ * Grouped: group g has its own x/w/bias/y pointers (cameras x forward passes), <= 8 groups.
+ * in_u8: x is uint8 and is scaled by 1/255 (correctly rounded) on load, serl/networks/pixel_multiplexer.py:27. */
+int serl_conv2d_fwd(int ngroups, const void* const* x, const float* const* w, const float* const* bias,
+                    float* const* y, int in_u8, int B, int IH, int IW, int C, int KH, int KW, int stride, int F,
+                    int relu, void* stream);
+/* dX = conv-transpose(dZ, W) masked by (xact > 0): the backward XLA derives for the same conv + ReLU stack. */
+int serl_conv2d_dgrad(int ngroups, const float* const* dz, const float* const* w, const float* const* xact,
+                      float* const* dx, int B, int IH, int IW, int C, int KH, int KW, int stride, int F, void* stream);
+/* dW, dbias of the same conv (split-K slabs in `workspace`, summed in a fixed order: reproducible). */
+long long serl_conv2d_wgrad_workspace_bytes(int ngroups, int B, int IH, int IW, int C, int KH, int KW, int stride,
+                                            int F);
+int serl_conv2d_wgrad(int ngroups, const void* const* x, const float* const* dz, float* const* dw,
+                      float* const* dbias, float* workspace, long long workspace_bytes, int in_u8, int B, int IH,
+                      int IW, int C, int KH, int KW, int stride, int F, void* stream);
+
+/* ---- SpatialLearnedEmbeddings, serl/networks/spatial.py:13-27 (F must be 8) */
+int serl_sle_fwd(const float* feat, const float* ker, float* out, int ldo, int B, int HW, int C, int F, void* stream);
+int serl_sle_bwd(const float* dout, int ldo, const float* ker, const float* feat, float* dfeat, float* dker, int B,
+                 int HW, int C, int F, void* stream);
+
+/* ---- batched / segmented dense GEMM: nn.Dense of serl/networks/mlp.py:21-25, pixel_multiplexer.py:34,39, the
+ * nn.vmap ensemble of serl/networks/ensemble.py:14-22 (nbatch = members) and their backward products.
+ * C[z][m][n] = sum_k A[z][m][k] B[z][k][n] (+bias[z][n]) (relu) ; element strides as named; k = seg*seglen + r. */
+int serl_gemm(const float* a, const float* b, float* c, const float* bias, int nbatch, int M, int N, int K, int seglen,
+              long long a_zs, long long a_ss, long long a_ms, long long a_ks, long long b_zs, long long b_ss,
+              long long b_ks, long long b_ns, long long c_zs, long long c_ms, long long bias_zs, int nsplit,
+              long long c_split_stride, int relu, int accumulate, int a_kcontig, int b_ncontig, void* stream);
+
+/* ---- bias + LayerNorm (flax eps 1e-6) + activation (0 none, 1 relu, 2 tanh): serl/networks/mlp.py:27-34,
+ * pixel_multiplexer.py:35-36,42-43; sums `nslab` split-K partials first. Rows are grouped per ensemble member. */
+int serl_ln_act_fwd(const float* pre, int nslab, long long pre_slab_stride, int ldpre, const float* bias,
+                    const float* gamma, const float* beta, long long param_group_stride, float* y, int ldy,
+                    float* xhat, float* rstd, int R, int N, int rows_per_group, int use_ln, int act, void* stream);
+int serl_ln_act_bwd(const float* dy, int lddy, const float* dq, const float* w_head, long long w_group_stride,
+                    const float* y, int ldy, const float* xhat, const float* rstd, const float* gamma,
+                    long long param_group_stride, float* dz, float* g, int R, int N, int rows_per_group, int use_ln,
+                    int act, void* stream);
+/* column sums over the batch (bias / LayerNorm / Dense(1) gradients), fixed order */
+int serl_colsum(const float* x0, const float* w, const float* mul, float* out0, const float* x1, float* out1,
+                const float* x2, const float* mul2, float* out2, int ngroups, int rows_per_group, int N, int ldx,
+                long long out_group_stride, void* stream);
+/* Dense(1) Q head + squeeze, serl/networks/state_action_value.py:17-19 */
+int serl_rowdot(const float* h, const float* w, long long w_group_stride, const float* b, long long b_group_stride,
+                float* q, int R, int N, int rows_per_group, void* stream);
+int serl_copy2d(float* dst, int ldd, const float* src, int lds, int rows, int cols, void* stream); /* jnp.concatenate */
+int serl_fill(float* p, float v, long long n, void* stream);
+
+/* ---- tanh-Gaussian policy head, serl/distributions/tanh_normal.py:29-48 + TFP MultivariateNormalDiag/Tanh;
+ * eps = jax.random.normal(key, (total_rows, A))[row_offset : row_offset + B] (threefry2x32, XLA erf_inv). */
+int serl_tanh_gaussian_fwd(const float* mean, const float* log_std_raw, int ld_ms, float* act, int ld_act, float* xpre,
+                           float* eps, float* logp, int B, int A, unsigned k0, unsigned k1, int row_offset,
+                           int total_rows, int deterministic, void* stream);
+int serl_tanh_gaussian_bwd(const float* act, int ld_act, const float* eps, const float* log_std_raw, int ld_ms,
+                           const float* da, int ld_da, const float* log_temp, float inv_batch, float* dmean,
+                           float* dlstd, int ld_out, int B, int A, void* stream);
+
+/* ---- TD target (ensemble min, optional entropy backup) + critic loss gradient, serl/agents/sac/sac_learner.py:185-209 */
+int serl_td_loss(const float* next_q, int Emin, const float* rew, const float* mask, const float* next_logp,
+                 const float* log_temp, float discount, const float* q, int E, int B, float inv_count, float* target,
+                 float* dq, float* info, void* stream);
+/* actor loss sums, sac_learner.py:135-139 */
+int serl_actor_loss(const float* q, int E, int B, const float* logp, const float* log_temp, float* info, void* stream);
+/* optax.adam + optax.incremental_update fused over a flat buffer, sac_learner.py:142,212-217 */
+int serl_adam_polyak(float* p, float* m, float* v, const float* g, float* target, long long n, float lr, float b1,
+                     float b2, float eps, float bc1, float bc2, float tau, float grad_scale, void* stream);
+/* temperature loss + scalar Adam, sac_learner.py:146-158, sac/temperature.py:9-14 */
+int serl_temperature_update(float* state, const float* sum_logp, float inv_batch, float target_entropy, float lr,
+                            float b1, float b2, float eps, float bc1, float bc2, float* info_out, void* stream);
+
+/* ---- replay gather + _unpack + DrQ random shift, uint8, bit-exact:
+ * serl/data/memory_efficient_replay_buffer.py:155-167, serl/utils/commons.py:16-24, serl/utils/augmentations.py:5-11,44-48.
+ * out (n,H,W,3*S)[.., c*S+s] = frame (t0+s) of sample j's T-frame window, shifted by off[j] - pad with edge clamp. */
+int serl_gather_crop_frames(const unsigned char* frames, long long cap, const long long* indx, int T, int t0,
+                            const int* off, unsigned char* out, int n, int H, int W, int S, int pad, void* stream);
+int serl_gather_crop_packed(const unsigned char* src, int T, int t0, const int* off, unsigned char* out, int n, int H,
+                            int W, int S, int pad, void* stream);
+int serl_gather_window(const unsigned char* frames, long long cap, const long long* indx, unsigned char* out, int n,
+                       int HW3, int S, void* stream);
+/* (dy,dx) = jax.random.randint(split(key, n_total)[row], (2,), 0, 2*pad+1), augmentations.py:6,46 */
+int serl_crop_offsets(unsigned k0, unsigned k1, int n, int row_offset, int n_total, int pad, int* out, void* stream);
+
+/* ---- host-side jax.random key plumbing (no GPU needed): split / bits / choice(replace=False),
+ * sac_learner.py:64,121-122,168-198; serl/networks/ensemble.py:28 */
+int serl_prng_split(unsigned k0, unsigned k1, int num, unsigned* out);
+int serl_prng_bits(unsigned k0, unsigned k1, int n, unsigned* out);
+int serl_prng_choice(unsigned k0, unsigned k1, int n, int m, int* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

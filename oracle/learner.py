@@ -180,9 +180,16 @@ def critic_qs(p, obs, actions, cfg, dtype):
 
 
 # --------------------------------------------------------------------------- distribution
-def tanh_normal_sample(mean, log_std, key):
-    """TFP MultivariateNormalDiag.sample -> Tanh bijector; eps = jax.random.normal(key, shape)."""
-    eps = torch.tensor(prng.normal(key, tuple(mean.shape)), dtype=mean.dtype)
+def tanh_normal_sample(mean, log_std, key, shard=None):
+    """TFP MultivariateNormalDiag.sample -> Tanh bijector; eps = jax.random.normal(key, shape).
+    shard=(row_offset, total_rows): this batch is rows [row_offset, row_offset+B) of a larger global batch
+    whose noise is one (total_rows, A) draw (data-parallel restatement, not in the reference)."""
+    if shard is None:
+        eps = prng.normal(key, tuple(mean.shape))
+    else:
+        off, total = shard
+        eps = prng.normal(key, (total,) + tuple(mean.shape[1:]))[off:off + mean.shape[0]]
+    eps = torch.tensor(eps, dtype=mean.dtype)
     x = mean + torch.exp(log_std) * eps
     return torch.tanh(x), x
 
@@ -245,14 +252,15 @@ def _slice_batch(batch, lo, hi):
 
 
 # --------------------------------------------------------------------------- SAC update
-def update_critic(state, cfg, batch, dtype=torch.float32):
-    """serl/agents/sac/sac_learner.py:160-219."""
+def update_critic(state, cfg, batch, dtype=torch.float32, shard=None):
+    """serl/agents/sac/sac_learner.py:160-219.  With shard=(row_offset, total_rows) the loss is this shard's
+    share sum((q-t)^2)/(E*total_rows) of the global mean, so shard gradients add up to the global one."""
     rng = state["rng"]
     ap = to_torch(state["actor"]["params"], dtype)
     with torch.no_grad():
         mean, log_std = actor_dist(ap, batch["next_observations"], cfg, dtype)   # :162-164
         key, rng = prng.split(rng)
-        next_a, next_x = tanh_normal_sample(mean, log_std, key)                  # :168-169
+        next_a, next_x = tanh_normal_sample(mean, log_std, key, shard)           # :168-169
         key, rng = prng.split(rng)
         tparams, indx = subsample_ensemble(key, state["target_critic"]["params"],
                                            cfg["num_min_qs"], cfg["num_qs"])     # :172-175
@@ -272,6 +280,8 @@ def update_critic(state, cfg, batch, dtype=torch.float32):
     act = torch.as_tensor(np.asarray(batch["actions"]), dtype=dtype)
     qs = critic_qs(cp, batch["observations"], act, cfg, dtype)
     loss = ((qs - target_q) ** 2).mean()                                          # :208
+    if shard is not None:
+        loss = ((qs - target_q) ** 2).sum() / (qs.shape[0] * shard[1])
     leaves = tree_leaves(cp)
     gl = torch.autograd.grad(loss, [t for _, t in leaves], allow_unused=True)
     grads = _rebuild(cp, [g if g is not None else torch.zeros_like(t)

@@ -14,7 +14,7 @@ from .dataset import Dataset
 
 def _alloc(space, capacity):
     if is_box(space):
-        return np.empty((capacity, *space.shape), dtype=space.dtype)
+        return np.zeros((capacity, *space.shape), dtype=space.dtype)   # zeros, not empty: wrapped demo windows (quirk C.7) stay deterministic
     if is_dict(space):
         return {k: _alloc(v, capacity) for k, v in space.spaces.items()}
     raise TypeError()
@@ -51,10 +51,10 @@ class ReplayBuffer(Dataset):
         data = dict(
             observations=_alloc(observation_space, capacity),
             next_observations=_alloc(next_observation_space, capacity),
-            actions=np.empty((capacity, *action_space.shape), dtype=action_space.dtype),
-            rewards=np.empty((capacity,), dtype=np.float32),
-            masks=np.empty((capacity,), dtype=np.float32),
-            dones=np.empty((capacity,), dtype=bool),
+            actions=np.zeros((capacity, *action_space.shape), dtype=action_space.dtype),
+            rewards=np.zeros((capacity,), dtype=np.float32),
+            masks=np.zeros((capacity,), dtype=np.float32),
+            dones=np.zeros((capacity,), dtype=bool),
         )
         super().__init__(data)
         self._size = 0
