@@ -54,6 +54,7 @@ struct ConvFwdP {
   struct BCol { uint32_t n; bool ok; };
   struct BK_ { uint32_t off; bool ok; };
   struct ORow { uint32_t base; };
+  struct OCol { float bias; };
   __device__ bool init(Ctx& c, int z) const { c.x = x[z]; c.w = w[z]; c.bias = bias[z]; c.y = y[z]; return true; }
   __device__ int M(const Ctx&) const { return g.B * g.OH * g.OW; }
   __device__ int N(const Ctx&) const { return g.F; }
@@ -72,20 +73,22 @@ struct ConvFwdP {
     const uint32_t ky = fd_div(kk, g.d_kwc);
     a.off = ky * (g.IW * g.C) + (kk - ky * (g.KW * g.C));
   }
-  __device__ float a_load(const Ctx& c, const ARow& r, const AK& a) const {
+  __device__ float a_load(const Ctx& c, const ARow& r, const AK& a, float& mul, float& add) const {
     const bool ok = r.ok && a.ok;
-    const float v = ld_in<U8>(c.x, ok ? r.base + a.off : 0u);
-    return ok ? v : 0.f;
+    mul = ok ? 1.f : 0.f; add = 0.f;
+    return ld_in<U8>(c.x, ok ? r.base + a.off : 0u);
   }
   __device__ void b_col(const Ctx&, int n, BCol& b) const { b.ok = n < g.F; b.n = b.ok ? n : 0; }
   __device__ void b_k(const Ctx&, int k, int kend, BK_& b) const { b.ok = k < kend; b.off = b.ok ? k * g.F : 0; }
-  __device__ float b_load(const Ctx& c, const BK_& k, const BCol& n) const {
-    const float v = c.w[k.off + n.n];
-    return (k.ok && n.ok) ? v : 0.f;
+  __device__ float b_load(const Ctx& c, const BK_& k, const BCol& n, float& mul) const {
+    mul = (k.ok && n.ok) ? 1.f : 0.f;
+    return c.w[k.off + n.n];
   }
+  __device__ void o_col(const Ctx& c, int n, OCol& o) const { o.bias = c.bias[n]; }
   __device__ void o_row(const Ctx&, int m, ORow& o) const { o.base = (uint32_t)m * g.F; }
-  __device__ void store(const Ctx& c, const ORow& o, int n, int, float v) const {
-    v += c.bias[n];
+  __device__ float o_aux(const Ctx&, const ORow&, int, int) const { return 0.f; }
+  __device__ void store(const Ctx& c, const ORow& o, const OCol& oc, int n, int, float v, float) const {
+    v += oc.bias;
     if (relu) v = fmaxf(v, 0.f);
     c.y[o.base + n] = v;
   }
@@ -115,6 +118,7 @@ struct ConvDgradP {
   struct BCol { uint32_t off; bool ok; };
   struct BK_ { uint32_t off; bool ok; };
   struct ORow { uint32_t base; };
+  struct OCol {};
   __device__ bool init(Ctx& c, int z) const {
     const int ci = z / G, gi = z - ci * G;
     c.dz = dz[gi]; c.w = w[gi]; c.xact = xact[gi]; c.dx = dx[gi];
@@ -143,11 +147,11 @@ struct ConvDgradP {
     a.jy = jy; a.jx = jx;
     a.off = (int)n - (int)((jy * g.OW + jx) * g.F);
   }
-  __device__ float a_load(const Ctx& c, const ARow& r, const AK& a) const {
+  __device__ float a_load(const Ctx& c, const ARow& r, const AK& a, float& mul, float& add) const {
     const int oy = r.iyp - a.jy, ox = r.ixp - a.jx;
     const bool ok = r.ok && a.ok && oy >= 0 && oy < g.OH && ox >= 0 && ox < g.OW;
-    const float v = c.dz[ok ? r.base + a.off : 0];
-    return ok ? v : 0.f;
+    mul = ok ? 1.f : 0.f; add = 0.f;
+    return c.dz[ok ? r.base + a.off : 0];
   }
   __device__ void b_col(const Ctx&, int n, BCol& b) const { b.ok = n < g.C; b.off = b.ok ? n * g.F : 0; }
   __device__ void b_k(const Ctx& c, int k, int kend, BK_& b) const {
@@ -158,19 +162,22 @@ struct ConvDgradP {
     const uint32_t ky = c.py + g.S * jy, kx = c.px + g.S * jx;
     b.off = ((ky * g.KW + kx) * g.C) * g.F + n;
   }
-  __device__ float b_load(const Ctx& c, const BK_& k, const BCol& n) const {
-    const float v = c.w[k.off + n.off];
-    return (k.ok && n.ok) ? v : 0.f;
+  __device__ float b_load(const Ctx& c, const BK_& k, const BCol& n, float& mul) const {
+    const bool ok = k.ok && n.ok;
+    mul = ok ? 1.f : 0.f;
+    return c.w[ok ? k.off + n.off : 0];
   }
   __device__ void o_row(const Ctx& c, int m, ORow& o) const {
     const uint32_t b = fd_div((uint32_t)m, c.d_hw), rem = m - b * (c.IHc * c.IWc);
     const uint32_t iyp = fd_div(rem, c.d_w), ixp = rem - iyp * c.IWc;
     o.base = ((b * g.IH + iyp * g.S + c.py) * g.IW + ixp * g.S + c.px) * g.C;
   }
-  __device__ void store(const Ctx& c, const ORow& o, int n, int, float v) const {
-    const uint32_t idx = o.base + n;
-    if (c.xact != nullptr) v = (c.xact[idx] > 0.f) ? v : 0.f;
-    c.dx[idx] = v;
+  __device__ void o_col(const Ctx&, int, OCol&) const {}
+  __device__ float o_aux(const Ctx& c, const ORow& o, int n, int) const {
+    return c.xact != nullptr ? c.xact[n >= 0 ? o.base + n : 0] : 1.f;
+  }
+  __device__ void store(const Ctx& c, const ORow& o, const OCol&, int n, int, float v, float aux) const {
+    c.dx[o.base + n] = aux > 0.f ? v : 0.f;
   }
 };
 
@@ -192,6 +199,7 @@ struct ConvWgradP {
   struct BCol { uint32_t n; bool ok; };
   struct BK_ { uint32_t off; bool ok; };
   struct ORow { uint32_t base; };
+  struct OCol {};
   __device__ bool init(Ctx& c, int z) const {
     c.x = x[z]; c.dz = dz[z];
     c.slab = slab + (size_t)z * nsplit * (size_t)(M(c) * g.F);
@@ -216,19 +224,22 @@ struct ConvWgradP {
     const uint32_t oy = fd_div(rem, g.d_ow), ox = rem - oy * g.OW;
     a.base = ((b * g.IH + oy * g.S) * g.IW + ox * g.S) * g.C;
   }
-  __device__ float a_load(const Ctx& c, const ARow& r, const AK& a) const {
+  __device__ float a_load(const Ctx& c, const ARow& r, const AK& a, float& mul, float& add) const {
     const bool ok = a.ok && r.kind == 1;
-    const float v = ld_in<U8>(c.x, ok ? a.base + r.off : 0u);
-    return ok ? v : ((a.ok && r.kind == 2) ? 1.f : 0.f);
+    mul = ok ? 1.f : 0.f;
+    add = (a.ok && r.kind == 2) ? 1.f : 0.f;     // the all-ones row that yields dbias
+    return ld_in<U8>(c.x, ok ? a.base + r.off : 0u);
   }
   __device__ void b_col(const Ctx&, int n, BCol& b) const { b.ok = n < g.F; b.n = b.ok ? n : 0; }
   __device__ void b_k(const Ctx&, int k, int kend, BK_& b) const { b.ok = k < kend; b.off = b.ok ? (uint32_t)k * g.F : 0; }
-  __device__ float b_load(const Ctx& c, const BK_& k, const BCol& n) const {
-    const float v = c.dz[k.off + n.n];
-    return (k.ok && n.ok) ? v : 0.f;
+  __device__ float b_load(const Ctx& c, const BK_& k, const BCol& n, float& mul) const {
+    mul = (k.ok && n.ok) ? 1.f : 0.f;
+    return c.dz[k.off + n.n];
   }
   __device__ void o_row(const Ctx&, int m, ORow& o) const { o.base = (uint32_t)m * g.F; }
-  __device__ void store(const Ctx& c, const ORow& o, int n, int split, float v) const {
+  __device__ void o_col(const Ctx&, int, OCol&) const {}
+  __device__ float o_aux(const Ctx&, const ORow&, int, int) const { return 0.f; }
+  __device__ void store(const Ctx& c, const ORow& o, const OCol&, int n, int split, float v, float) const {
     c.slab[(size_t)split * (size_t)((KKC() + 1) * g.F) + o.base + n] = v;
   }
 };

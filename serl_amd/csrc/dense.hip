@@ -28,6 +28,7 @@ struct GemmP {
   struct BCol { long long off; bool ok; };
   struct BK_ { long long off; bool ok; };
   struct ORow { long long off; };
+  struct OCol { float bias; };
   __device__ bool init(Ctx& c, int z) const {
     c.a = g.a + z * g.a_zs; c.b = g.b + z * g.b_zs; c.c = g.c + z * g.c_zs;
     c.bias = g.bias ? g.bias + z * g.bias_zs : nullptr;
@@ -44,10 +45,10 @@ struct GemmP {
     const uint32_t seg = fd_div(kk, g.d_seg), r = kk - seg * g.seglen;
     a.off = seg * g.a_ss + r * g.a_ks;
   }
-  __device__ float a_load(const Ctx& c, const ARow& r, const AK& a) const {
+  __device__ float a_load(const Ctx& c, const ARow& r, const AK& a, float& mul, float& add) const {
     const bool ok = r.ok && a.ok;
-    const float v = c.a[ok ? r.off + a.off : 0];
-    return ok ? v : 0.f;
+    mul = ok ? 1.f : 0.f; add = 0.f;
+    return c.a[ok ? r.off + a.off : 0];
   }
   __device__ void b_col(const Ctx&, int n, BCol& b) const { b.ok = n < g.N; b.off = b.ok ? n * g.b_ns : 0; }
   __device__ void b_k(const Ctx&, int k, int kend, BK_& b) const {
@@ -56,18 +57,20 @@ struct GemmP {
     const uint32_t seg = fd_div(kk, g.d_seg), r = kk - seg * g.seglen;
     b.off = seg * g.b_ss + r * g.b_ks;
   }
-  __device__ float b_load(const Ctx& c, const BK_& k, const BCol& n) const {
+  __device__ float b_load(const Ctx& c, const BK_& k, const BCol& n, float& mul) const {
     const bool ok = k.ok && n.ok;
-    const float v = c.b[ok ? k.off + n.off : 0];
-    return ok ? v : 0.f;
+    mul = ok ? 1.f : 0.f;
+    return c.b[ok ? k.off + n.off : 0];
   }
   __device__ void o_row(const Ctx&, int m, ORow& o) const { o.off = m * g.c_ms; }
-  __device__ void store(const Ctx& c, const ORow& o, int n, int split, float v) const {
-    float* dst = c.c + split * g.c_ss + o.off + n;
-    if (c.bias) v += c.bias[n];
-    if (g.accumulate) v += *dst;
+  __device__ void o_col(const Ctx& c, int n, OCol& o) const { o.bias = c.bias ? c.bias[n] : 0.f; }
+  __device__ float o_aux(const Ctx& c, const ORow& o, int n, int split) const {
+    return g.accumulate ? c.c[n >= 0 ? split * g.c_ss + o.off + n : 0] : 0.f;
+  }
+  __device__ void store(const Ctx& c, const ORow& o, const OCol& oc, int n, int split, float v, float aux) const {
+    v += oc.bias + aux;
     if (g.relu) v = fmaxf(v, 0.f);
-    *dst = v;
+    c.c[split * g.c_ss + o.off + n] = v;
   }
 };
 

@@ -29,16 +29,22 @@ struct TileCfg {
 //   static constexpr bool A_KCONTIG, B_NCONTIG;       (which axis is contiguous in memory)
 //   bool init(Ctx&, int z) const;                     (false -> block has nothing to do)
 //   int  M(ctx), N(ctx), K(ctx);  int ksplit_len() const;
-//   void a_row(ctx, m, ARow&); void a_k(ctx, k, kend, AK&); float a_load(ctx, ARow, AK);
-//   void b_col(ctx, n, BCol&); void b_k(ctx, k, kend, BK_&); float b_load(ctx, BK_, BCol);
-//   void store(ctx, m, n, split, float v);
+//   void a_row(ctx, m, ARow&); void a_k(ctx, k, kend, AK&); float a_load(ctx, ARow, AK, float& mul, float& add);
+//   void b_col(ctx, n, BCol&); void b_k(ctx, k, kend, BK_&); float b_load(ctx, BK_, BCol, float& mul);
+//   a_load / b_load return the RAW value of an unconditional load from a clamped (always valid) address; the
+//   element is raw*mul+add (mul = 0 outside the matrix).  The mask is applied when the slab is written to
+//   LDS, after the MFMAs, so the prefetch stays in flight behind them -- a select on the loaded value makes
+//   hipcc branch around every load with a vmcnt(0) each (CDNA guide, "register or load" trap).
+//   epilogue: void o_col(ctx, n, OCol&) (per-column context, e.g. bias; n is valid); void o_row(ctx, m, ORow&);
+//   float o_aux(ctx, ORow, n_or_-1, split) (per-element auxiliary LOAD, clamped when n < 0; 0 if unused);
+//   void store(ctx, ORow, OCol, n, split, float v, float aux).
 template <class P, class T>
 __global__ __launch_bounds__(256) void igemm_kernel(const P p) {
   constexpr int BM = T::BM, BN = T::BN, BK = T::BK, TM = T::TM, TN = T::TN;
   constexpr int LDA = BM + 4, LDB = BN + 4;
   constexpr int NA = BM * BK / 256, NB = BN * BK / 256;
-  __shared__ float As[BK * LDA];
-  __shared__ float Bs[BK * LDB];
+  __shared__ float As[2 * BK * LDA];
+  __shared__ float Bs[2 * BK * LDB];
 
   typename P::Ctx ctx;
   if (!p.init(ctx, blockIdx.z)) return;
@@ -80,19 +86,19 @@ __global__ __launch_bounds__(256) void igemm_kernel(const P p) {
     for (int i = 0; i < NB; ++i) p.b_col(ctx, n0 + b_nl + i * (256 / BK), bcol[i]);
   }
 
-  float areg[NA], breg[NB];
+  float areg[NA], breg[NB], amul[NA], aadd[NA], bmul[NB];
   auto gload = [&](int k0) {
     if constexpr (P::A_KCONTIG) {
       typename P::AK ak;
       p.a_k(ctx, k0 + a_kl, kend, ak);
 #pragma unroll
-      for (int i = 0; i < NA; ++i) areg[i] = p.a_load(ctx, arow[i], ak);
+      for (int i = 0; i < NA; ++i) areg[i] = p.a_load(ctx, arow[i], ak, amul[i], aadd[i]);
     } else {
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
         typename P::AK ak;
         p.a_k(ctx, k0 + a_kl + i * (256 / BM), kend, ak);
-        areg[i] = p.a_load(ctx, arow[0], ak);
+        areg[i] = p.a_load(ctx, arow[0], ak, amul[i], aadd[i]);
       }
     }
     if constexpr (P::B_NCONTIG) {
@@ -100,29 +106,31 @@ __global__ __launch_bounds__(256) void igemm_kernel(const P p) {
       for (int i = 0; i < NB; ++i) {
         typename P::BK_ bk;
         p.b_k(ctx, k0 + b_kl + i * (256 / BN), kend, bk);
-        breg[i] = p.b_load(ctx, bk, bcol[0]);
+        breg[i] = p.b_load(ctx, bk, bcol[0], bmul[i]);
       }
     } else {
       typename P::BK_ bk;
       p.b_k(ctx, k0 + b_kl, kend, bk);
 #pragma unroll
-      for (int i = 0; i < NB; ++i) breg[i] = p.b_load(ctx, bk, bcol[i]);
+      for (int i = 0; i < NB; ++i) breg[i] = p.b_load(ctx, bk, bcol[i], bmul[i]);
     }
   };
-  auto lstore = [&]() {
+  auto lstore = [&](int buf) {
+    float* As_ = As + buf * (BK * LDA);
+    float* Bs_ = Bs + buf * (BK * LDB);
     if constexpr (P::A_KCONTIG) {
 #pragma unroll
-      for (int i = 0; i < NA; ++i) As[a_kl * LDA + a_ml + i * (256 / BK)] = areg[i];
+      for (int i = 0; i < NA; ++i) As_[a_kl * LDA + a_ml + i * (256 / BK)] = fmaf(areg[i], amul[i], aadd[i]);
     } else {
 #pragma unroll
-      for (int i = 0; i < NA; ++i) As[(a_kl + i * (256 / BM)) * LDA + a_ml] = areg[i];
+      for (int i = 0; i < NA; ++i) As_[(a_kl + i * (256 / BM)) * LDA + a_ml] = fmaf(areg[i], amul[i], aadd[i]);
     }
     if constexpr (P::B_NCONTIG) {
 #pragma unroll
-      for (int i = 0; i < NB; ++i) Bs[(b_kl + i * (256 / BN)) * LDB + b_nl] = breg[i];
+      for (int i = 0; i < NB; ++i) Bs_[(b_kl + i * (256 / BN)) * LDB + b_nl] = breg[i] * bmul[i];
     } else {
 #pragma unroll
-      for (int i = 0; i < NB; ++i) Bs[b_kl * LDB + b_nl + i * (256 / BK)] = breg[i];
+      for (int i = 0; i < NB; ++i) Bs_[b_kl * LDB + b_nl + i * (256 / BK)] = breg[i] * bmul[i];
     }
   };
 
@@ -134,14 +142,18 @@ __global__ __launch_bounds__(256) void igemm_kernel(const P p) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
+  // LDS is double-buffered: the slab of step t+1 is written into the other buffer right after the MFMAs of
+  // step t, so one barrier per K-step suffices.
   gload(kbeg);
-  lstore();
+  lstore(0);
   __syncthreads();
-  const float* Ap = As + h * LDA + wm * (TM * 32) + r;
-  const float* Bp = Bs + h * LDB + wn * (TN * 32) + r;
+  int cur = 0;
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
     const bool more = (k0 + BK) < kend;
     if (more) gload(k0 + BK);
+    __builtin_amdgcn_sched_barrier(0);   // loads are issued above, consumed (masked + written to LDS) below the MFMAs
+    const float* Ap = As + cur * (BK * LDA) + h * LDA + wm * (TM * 32) + r;
+    const float* Bp = Bs + cur * (BK * LDB) + h * LDB + wn * (TN * 32) + r;
 #pragma unroll
     for (int kk = 0; kk < BK / 2; ++kk) {
       float a[TM], b[TN];
@@ -155,28 +167,40 @@ __global__ __launch_bounds__(256) void igemm_kernel(const P p) {
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) lstore(cur ^ 1);
     __syncthreads();
-    if (more) {
-      lstore();
-      __syncthreads();
-    }
+    cur ^= 1;
   }
 
-  // ---- epilogue: C/D map of the 32x32 tile: col = lane&31, row = (q&3) + 8*(q>>2) + 4*(lane>>5)
+  // ---- epilogue: C/D map of the 32x32 tile: col = lane&31, row = (q&3) + 8*(q>>2) + 4*(lane>>5).
+  // Column context (bias) is fetched once per column; per-element auxiliary loads (ReLU mask source,
+  // accumulate target) are issued for a whole 32x32 tile before the first store so they overlap.
+  typename P::OCol ocol[TN];
+  int ncol[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    ncol[j] = n0 + wn * (TN * 32) + j * 32 + r;
+    p.o_col(ctx, ncol[j] < N ? ncol[j] : 0, ocol[j]);
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
+    typename P::ORow orow[16];
+    float aux[16][TN];
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       const int m = m0 + wm * (TM * 32) + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-      if (m < M) {
-        typename P::ORow orow;
-        p.o_row(ctx, m, orow);
+      p.o_row(ctx, m < M ? m : 0, orow[q]);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const int n = n0 + wn * (TN * 32) + j * 32 + r;
-          if (n < N) p.store(ctx, orow, n, split, acc[i][j][q]);
-        }
-      }
+      for (int j = 0; j < TN; ++j)
+        aux[q][j] = p.o_aux(ctx, orow[q], (m < M && ncol[j] < N) ? ncol[j] : -1, split);
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int m = m0 + wm * (TM * 32) + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        if (m < M && ncol[j] < N) p.store(ctx, orow[q], ocol[j], ncol[j], split, acc[i][j][q], aux[q][j]);
     }
   }
 }
