@@ -269,9 +269,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const ReduceArgs a) {
 }
 
 // ------------------------------------------------------------------------------ host API
-typedef TileCfg<128, 128, 16, 2, 2> T128x128;
-typedef TileCfg<128, 64, 16, 2, 2> T128x64;
-typedef TileCfg<128, 32, 16, 4, 1> T128x32;
+#ifndef CONV_BK
+#define CONV_BK 16
+#endif
+typedef TileCfg<128, 128, CONV_BK, 2, 2> T128x128;
+typedef TileCfg<128, 64, CONV_BK, 2, 2> T128x64;
+typedef TileCfg<128, 32, CONV_BK, 4, 1> T128x32;
 
 template <class P>
 static int launch_by_n(const P& p, int max_m, int n, int nsplit, int nz, hipStream_t st, const char* name) {
@@ -332,7 +335,7 @@ static void wgrad_plan(const ConvGeom& g, int ngroups, int& nsplit, int& klen) {
   const int tiles = cdiv(kkc1, 128) * cdiv(g.F, bn) * ngroups;
   int want = cdiv(1024, tiles);
   if (want < 1) want = 1;
-  klen = cdiv(cdiv(Kr, want), 16) * 16;
+  klen = cdiv(cdiv(Kr, want), CONV_BK) * CONV_BK;
   if (klen < 64) klen = 64;
   nsplit = cdiv(Kr, klen);
 }

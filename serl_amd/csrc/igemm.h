@@ -14,6 +14,9 @@
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+#ifndef IGEMM_MIN_WAVES
+#define IGEMM_MIN_WAVES 3
+#endif
 
 template <int BM_, int BN_, int BK_, int WGM_, int WGN_>
 struct TileCfg {
@@ -39,7 +42,7 @@ struct TileCfg {
 //   float o_aux(ctx, ORow, n_or_-1, split) (per-element auxiliary LOAD, clamped when n < 0; 0 if unused);
 //   void store(ctx, ORow, OCol, n, split, float v, float aux).
 template <class P, class T>
-__global__ __launch_bounds__(256) void igemm_kernel(const P p) {
+__global__ __launch_bounds__(256, IGEMM_MIN_WAVES) void igemm_kernel(const P p) {
   constexpr int BM = T::BM, BN = T::BN, BK = T::BK, TM = T::TM, TN = T::TN;
   constexpr int LDA = BM + 4, LDB = BN + 4;
   constexpr int NA = BM * BK / 256, NB = BN * BK / 256;
@@ -73,11 +76,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(const P p) {
   } else {
     a_ml = tid % BM;
     a_kl = tid / BM;
+    // a wave covers 64 consecutive m of ONE k: make that provable so the k-side index math runs on the SALU
+    if constexpr (BM % 64 == 0) a_kl = __builtin_amdgcn_readfirstlane(a_kl);
     p.a_row(ctx, m0 + a_ml, arow[0]);
   }
   if constexpr (P::B_NCONTIG) {
     b_nl = tid % BN;
     b_kl = tid / BN;
+    if constexpr (BN % 64 == 0) b_kl = __builtin_amdgcn_readfirstlane(b_kl);
     p.b_col(ctx, n0 + b_nl, bcol[0]);
   } else {
     b_kl = tid % BK;

@@ -1,0 +1,58 @@
+"""Micro-benchmark of the igemm conv launches at the headline shapes (B=256, E1 encoder): TFLOP/s per
+launch, measured with HIP events.  python tools/bench_conv.py [B]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from serl_amd import ops  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+dev = torch.device("cuda")
+LAYERS = [(128, 9, 32), (63, 32, 64), (31, 64, 128), (15, 128, 256)]   # IH, C, F  (3x3, stride 2)
+st = ops.current_stream()
+
+
+def timeit(fn, n=20):
+    fn(); torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / n
+
+
+tot = 0.0
+for li, (IH, C, F) in enumerate(LAYERS):
+    OH = (IH - 3) // 2 + 1
+    flop1 = 2.0 * B * OH * OH * F * 9 * C
+    for G, what in ((6, "fwd"), (2, "wgrad"), (2, "dgrad")):
+        if what == "dgrad" and li == 0:
+            continue
+        if li == 0:
+            xs = [torch.randint(0, 256, (B, IH, IH, C), dtype=torch.uint8, device=dev) for _ in range(G)]
+        else:
+            xs = [torch.rand((B, IH, IH, C), device=dev) for _ in range(G)]
+        ws = [torch.randn((3, 3, C, F), device=dev) * 0.05 for _ in range(G)]
+        bs = [torch.zeros(F, device=dev) for _ in range(G)]
+        ys = [torch.empty((B, OH, OH, F), device=dev) for _ in range(G)]
+        dz = [torch.randn((B, OH, OH, F), device=dev) for _ in range(G)]
+        p = lambda ts: [t.data_ptr() for t in ts]
+        if what == "fwd":
+            fn = lambda: ops.conv2d_fwd(p(xs), p(ws), p(bs), p(ys), li == 0, B, IH, IH, C, 3, 3, 2, F, True, st)
+        elif what == "wgrad":
+            nb = ops.conv2d_wgrad_workspace_bytes(G, B, IH, IH, C, 3, 3, 2, F)
+            wk = torch.empty(nb // 4, device=dev)
+            dws = [torch.empty_like(w) for w in ws]
+            fn = lambda: ops.conv2d_wgrad(p(xs), p(dz), p(dws), p(bs), wk.data_ptr(), nb, li == 0, B, IH, IH, C, 3, 3,
+                                          2, F, st)
+        else:
+            dxs = [torch.empty_like(x) for x in xs]
+            fn = lambda: ops.conv2d_dgrad(p(dz), p(ws), p(xs), p(dxs), B, IH, IH, C, 3, 3, 2, F, st)
+        ms = timeit(fn)
+        per_step = ms * (1 if what == "fwd" else 1)
+        tot += per_step
+        print(f"conv{li + 1} {what:5s} G={G}: {ms * 1e3:8.1f} us  {flop1 * G / ms / 1e9:7.1f} TFLOP/s")
+print(f"sum of one fwd(6 groups)+wgrad+dgrad per layer: {tot:.3f} ms per grad-step (ideal {301e9 / 157.3e12 * 1e3:.2f})")
