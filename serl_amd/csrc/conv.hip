@@ -32,16 +32,25 @@ __device__ __forceinline__ float u8_to_unit(unsigned char v) {
   return fmaf(rem, rcp, q);
 }
 
-template <bool U8>
-__device__ __forceinline__ float ld_in(const void* p, uint32_t idx) {
-  if constexpr (U8) return u8_to_unit(((const unsigned char*)p)[idx]);
-  else return ((const float*)p)[idx];
+template <bool U8, int V>
+__device__ __forceinline__ void ld_in(const void* p, uint32_t idx, VecF<V>& o) {
+  if constexpr (U8) {
+    static_assert(V == 1, "uint8 input is loaded bytewise");
+    o.v[0] = u8_to_unit(((const unsigned char*)p)[idx]);
+  } else {
+    ld_vec<V>((const float*)p + idx, o);
+  }
+}
+template <int V> __device__ __forceinline__ void zero_vec(VecF<V>& o) {
+#pragma unroll
+  for (int j = 0; j < V; ++j) o.v[j] = 0.f;
 }
 
 // ------------------------------------------------------------------------------ forward
-template <bool U8>
+template <bool U8, int V>
 struct ConvFwdP {
   static constexpr bool A_KCONTIG = true, B_NCONTIG = true;
+  static constexpr int VA = V, VB = V;
   ConvGeom g;
   const void* x[MAXG];
   const float* w[MAXG];
@@ -73,16 +82,16 @@ struct ConvFwdP {
     const uint32_t ky = fd_div(kk, g.d_kwc);
     a.off = ky * (g.IW * g.C) + (kk - ky * (g.KW * g.C));
   }
-  __device__ float a_load(const Ctx& c, const ARow& r, const AK& a, float& mul, float& add) const {
+  __device__ void a_load(const Ctx& c, const ARow& r, const AK& a, VecF<V>& raw, float& mul, VecF<V>& add) const {
     const bool ok = r.ok && a.ok;
-    mul = ok ? 1.f : 0.f; add = 0.f;
-    return ld_in<U8>(c.x, ok ? r.base + a.off : 0u);
+    mul = ok ? 1.f : 0.f; zero_vec(add);
+    ld_in<U8, V>(c.x, ok ? r.base + a.off : 0u, raw);
   }
   __device__ void b_col(const Ctx&, int n, BCol& b) const { b.ok = n < g.F; b.n = b.ok ? n : 0; }
   __device__ void b_k(const Ctx&, int k, int kend, BK_& b) const { b.ok = k < kend; b.off = b.ok ? k * g.F : 0; }
-  __device__ float b_load(const Ctx& c, const BK_& k, const BCol& n, float& mul) const {
+  __device__ void b_load(const Ctx& c, const BK_& k, const BCol& n, VecF<V>& raw, float& mul) const {
     mul = (k.ok && n.ok) ? 1.f : 0.f;
-    return c.w[k.off + n.n];
+    ld_vec<V>(c.w + k.off + n.n, raw);
   }
   __device__ void o_col(const Ctx& c, int n, OCol& o) const { o.bias = c.bias[n]; }
   __device__ void o_row(const Ctx&, int m, ORow& o) const { o.base = (uint32_t)m * g.F; }
@@ -97,8 +106,10 @@ struct ConvFwdP {
 // ------------------------------------------------------------------------------ dgrad
 // dX[b,iy,ix,c] = sum_{ky,kx,n} dZ[b,(iy-ky)/S,(ix-kx)/S,n] * W[ky,kx,c,n]; input pixels are split in
 // S*S parity classes so that every class is a dense GEMM over its own taps (no wasted MACs).
+template <int V>
 struct ConvDgradP {
   static constexpr bool A_KCONTIG = true, B_NCONTIG = false;
+  static constexpr int VA = V, VB = V;
   ConvGeom g;
   int G;
   const float* dz[MAXG];
@@ -147,11 +158,11 @@ struct ConvDgradP {
     a.jy = jy; a.jx = jx;
     a.off = (int)n - (int)((jy * g.OW + jx) * g.F);
   }
-  __device__ float a_load(const Ctx& c, const ARow& r, const AK& a, float& mul, float& add) const {
+  __device__ void a_load(const Ctx& c, const ARow& r, const AK& a, VecF<V>& raw, float& mul, VecF<V>& add) const {
     const int oy = r.iyp - a.jy, ox = r.ixp - a.jx;
     const bool ok = r.ok && a.ok && oy >= 0 && oy < g.OH && ox >= 0 && ox < g.OW;
-    mul = ok ? 1.f : 0.f; add = 0.f;
-    return c.dz[ok ? r.base + a.off : 0];
+    mul = ok ? 1.f : 0.f; zero_vec(add);
+    ld_vec<V>(c.dz + (ok ? r.base + a.off : 0), raw);
   }
   __device__ void b_col(const Ctx&, int n, BCol& b) const { b.ok = n < g.C; b.off = b.ok ? n * g.F : 0; }
   __device__ void b_k(const Ctx& c, int k, int kend, BK_& b) const {
@@ -162,10 +173,10 @@ struct ConvDgradP {
     const uint32_t ky = c.py + g.S * jy, kx = c.px + g.S * jx;
     b.off = ((ky * g.KW + kx) * g.C) * g.F + n;
   }
-  __device__ float b_load(const Ctx& c, const BK_& k, const BCol& n, float& mul) const {
+  __device__ void b_load(const Ctx& c, const BK_& k, const BCol& n, VecF<V>& raw, float& mul) const {
     const bool ok = k.ok && n.ok;
     mul = ok ? 1.f : 0.f;
-    return c.w[ok ? k.off + n.off : 0];
+    ld_vec<V>(c.w + (ok ? k.off + n.off : 0), raw);
   }
   __device__ void o_row(const Ctx& c, int m, ORow& o) const {
     const uint32_t b = fd_div((uint32_t)m, c.d_hw), rem = m - b * (c.IHc * c.IWc);
@@ -185,9 +196,10 @@ struct ConvDgradP {
 // dW[(ky,kx,c)][n] = sum_{b,oy,ox} X[b,oy*S+ky,ox*S+kx,c] * dZ[b,oy,ox,n]; one extra all-ones row of
 // the virtual A yields dbias[n] = sum dZ for free.  The long reduction is split over blockIdx.y into
 // slabs that a second kernel sums in a fixed order (bitwise reproducible, no atomics).
-template <bool U8>
+template <bool U8, int V>
 struct ConvWgradP {
   static constexpr bool A_KCONTIG = false, B_NCONTIG = true;
+  static constexpr int VA = V, VB = V;
   ConvGeom g;
   const void* x[MAXG];
   const float* dz[MAXG];
@@ -224,17 +236,18 @@ struct ConvWgradP {
     const uint32_t oy = fd_div(rem, g.d_ow), ox = rem - oy * g.OW;
     a.base = ((b * g.IH + oy * g.S) * g.IW + ox * g.S) * g.C;
   }
-  __device__ float a_load(const Ctx& c, const ARow& r, const AK& a, float& mul, float& add) const {
+  __device__ void a_load(const Ctx& c, const ARow& r, const AK& a, VecF<V>& raw, float& mul, VecF<V>& add) const {
     const bool ok = a.ok && r.kind == 1;
     mul = ok ? 1.f : 0.f;
-    add = (a.ok && r.kind == 2) ? 1.f : 0.f;     // the all-ones row that yields dbias
-    return ld_in<U8>(c.x, ok ? a.base + r.off : 0u);
+    zero_vec(add);
+    add.v[0] = (a.ok && r.kind == 2) ? 1.f : 0.f;     // the all-ones row (first of its vector) that yields dbias
+    ld_in<U8, V>(c.x, ok ? a.base + r.off : 0u, raw);
   }
   __device__ void b_col(const Ctx&, int n, BCol& b) const { b.ok = n < g.F; b.n = b.ok ? n : 0; }
   __device__ void b_k(const Ctx&, int k, int kend, BK_& b) const { b.ok = k < kend; b.off = b.ok ? (uint32_t)k * g.F : 0; }
-  __device__ float b_load(const Ctx& c, const BK_& k, const BCol& n, float& mul) const {
+  __device__ void b_load(const Ctx& c, const BK_& k, const BCol& n, VecF<V>& raw, float& mul) const {
     mul = (k.ok && n.ok) ? 1.f : 0.f;
-    return c.dz[k.off + n.n];
+    ld_vec<V>(c.dz + k.off + n.n, raw);
   }
   __device__ void o_row(const Ctx&, int m, ORow& o) const { o.base = (uint32_t)m * g.F; }
   __device__ void o_col(const Ctx&, int, OCol&) const {}
@@ -283,6 +296,12 @@ static int launch_by_n(const P& p, int max_m, int n, int nsplit, int nz, hipStre
   return igemm_launch<P, T128x128>(p, max_m, n, nsplit, nz, st, name);
 }
 
+static bool aligned16(const void* const* ps, int n) {
+  for (int i = 0; i < n; ++i)
+    if (((uintptr_t)ps[i]) & 15) return false;
+  return true;
+}
+
 extern "C" int serl_conv2d_fwd(int ngroups, const void* const* x, const float* const* w, const float* const* bias,
                                float* const* y, int in_u8, int B, int IH, int IW, int C, int KH, int KW, int stride,
                                int F, int relu, void* stream) {
@@ -291,15 +310,36 @@ extern "C" int serl_conv2d_fwd(int ngroups, const void* const* x, const float* c
   if (int e = make_geom(g, B, IH, IW, C, KH, KW, stride, F)) return e;
   const int M = B * g.OH * g.OW;
   hipStream_t st = (hipStream_t)stream;
-  if (in_u8) {
-    ConvFwdP<true> p; p.g = g; p.relu = relu;
-    for (int i = 0; i < ngroups; ++i) { p.x[i] = x[i]; p.w[i] = w[i]; p.bias[i] = bias[i]; p.y[i] = y[i]; }
-    return launch_by_n(p, M, F, 1, ngroups, st, "conv2d_fwd_u8");
-  } else {
-    ConvFwdP<false> p; p.g = g; p.relu = relu;
-    for (int i = 0; i < ngroups; ++i) { p.x[i] = x[i]; p.w[i] = w[i]; p.bias[i] = bias[i]; p.y[i] = y[i]; }
-    return launch_by_n(p, M, F, 1, ngroups, st, "conv2d_fwd_f32");
+  const bool v4 = !in_u8 && C % 4 == 0 && F % 4 == 0 && aligned16(x, ngroups) &&
+                  aligned16((const void* const*)w, ngroups);
+#define FILL(p) p.g = g; p.relu = relu; \
+  for (int i = 0; i < ngroups; ++i) { p.x[i] = x[i]; p.w[i] = w[i]; p.bias[i] = bias[i]; p.y[i] = y[i]; }
+  if (in_u8) { ConvFwdP<true, 1> p; FILL(p) return launch_by_n(p, M, F, 1, ngroups, st, "conv2d_fwd_u8"); }
+  if (v4) { ConvFwdP<false, 4> p; FILL(p) return launch_by_n(p, M, F, 1, ngroups, st, "conv2d_fwd_f32x4"); }
+  ConvFwdP<false, 1> p; FILL(p) return launch_by_n(p, M, F, 1, ngroups, st, "conv2d_fwd_f32");
+#undef FILL
+}
+
+template <int V>
+static int dgrad_go(const ConvGeom& g, int ngroups, const float* const* dz, const float* const* w,
+                    const float* const* xact, float* const* dx, int stride, hipStream_t st) {
+  ConvDgradP<V> p; p.g = g; p.G = ngroups;
+  p.d_f_ = make_fastdiv(g.F);
+  for (int ci = 0; ci < stride * stride; ++ci) {
+    typename ConvDgradP<V>::Cls& k = p.cls[ci];
+    k.py = ci / stride; k.px = ci - k.py * stride;
+    k.IHc = (g.IH - k.py + stride - 1) / stride;
+    k.IWc = (g.IW - k.px + stride - 1) / stride;
+    k.TY = (g.KH - k.py + stride - 1) / stride;
+    k.TX = (g.KW - k.px + stride - 1) / stride;
+    if (k.TY <= 0 || k.TX <= 0) { k.TY = 0; k.TX = 0; }   // class gets no gradient: K = 0 -> zeros
+    k.d_hw = make_fastdiv(k.IHc * k.IWc > 0 ? k.IHc * k.IWc : 1);
+    k.d_w = make_fastdiv(k.IWc > 0 ? k.IWc : 1);
+    k.d_tx = make_fastdiv(k.TX > 0 ? k.TX : 1);
   }
+  for (int i = 0; i < ngroups; ++i) { p.dz[i] = dz[i]; p.w[i] = w[i]; p.xact[i] = xact ? xact[i] : nullptr; p.dx[i] = dx[i]; }
+  const int max_m = g.B * cdiv(g.IH, stride) * cdiv(g.IW, stride);
+  return launch_by_n(p, max_m, g.C, 1, ngroups * stride * stride, st, "conv2d_dgrad");
 }
 
 extern "C" int serl_conv2d_dgrad(int ngroups, const float* const* dz, const float* const* w, const float* const* xact,
@@ -309,23 +349,9 @@ extern "C" int serl_conv2d_dgrad(int ngroups, const float* const* dz, const floa
   ConvGeom g;
   if (int e = make_geom(g, B, IH, IW, C, KH, KW, stride, F)) return e;
   SERL_CHECK_ARG(stride <= 2, "conv2d_dgrad: stride must be 1 or 2");
-  ConvDgradP p; p.g = g; p.G = ngroups;
-  p.d_f_ = make_fastdiv(F);
-  for (int ci = 0; ci < stride * stride; ++ci) {
-    ConvDgradP::Cls& k = p.cls[ci];
-    k.py = ci / stride; k.px = ci - k.py * stride;
-    k.IHc = (IH - k.py + stride - 1) / stride;
-    k.IWc = (IW - k.px + stride - 1) / stride;
-    k.TY = (KH - k.py + stride - 1) / stride;
-    k.TX = (KW - k.px + stride - 1) / stride;
-    if (k.TY <= 0 || k.TX <= 0) { k.TY = 0; k.TX = 0; }   // class gets no gradient: K = 0 -> zeros
-    k.d_hw = make_fastdiv(k.IHc * k.IWc > 0 ? k.IHc * k.IWc : 1);
-    k.d_w = make_fastdiv(k.IWc > 0 ? k.IWc : 1);
-    k.d_tx = make_fastdiv(k.TX > 0 ? k.TX : 1);
-  }
-  for (int i = 0; i < ngroups; ++i) { p.dz[i] = dz[i]; p.w[i] = w[i]; p.xact[i] = xact ? xact[i] : nullptr; p.dx[i] = dx[i]; }
-  const int max_m = B * cdiv(IH, stride) * cdiv(IW, stride);
-  return launch_by_n(p, max_m, C, 1, ngroups * stride * stride, (hipStream_t)stream, "conv2d_dgrad");
+  const bool v4 = F % 4 == 0 && aligned16((const void* const*)dz, ngroups) && aligned16((const void* const*)w, ngroups);
+  if (v4) return dgrad_go<4>(g, ngroups, dz, w, xact, dx, stride, (hipStream_t)stream);
+  return dgrad_go<1>(g, ngroups, dz, w, xact, dx, stride, (hipStream_t)stream);
 }
 
 static void wgrad_plan(const ConvGeom& g, int ngroups, int& nsplit, int& klen) {
@@ -363,15 +389,14 @@ extern "C" int serl_conv2d_wgrad(int ngroups, const void* const* x, const float*
                  workspace_bytes, need);
   hipStream_t st = (hipStream_t)stream;
   int e;
-  if (in_u8) {
-    ConvWgradP<true> p; p.g = g; p.slab = workspace; p.nsplit = nsplit; p.klen = klen;
-    for (int i = 0; i < ngroups; ++i) { p.x[i] = x[i]; p.dz[i] = dz[i]; }
-    e = launch_by_n(p, kkc + 1, F, nsplit, ngroups, st, "conv2d_wgrad_u8");
-  } else {
-    ConvWgradP<false> p; p.g = g; p.slab = workspace; p.nsplit = nsplit; p.klen = klen;
-    for (int i = 0; i < ngroups; ++i) { p.x[i] = x[i]; p.dz[i] = dz[i]; }
-    e = launch_by_n(p, kkc + 1, F, nsplit, ngroups, st, "conv2d_wgrad_f32");
-  }
+  const bool v4 = !in_u8 && C % 4 == 0 && F % 4 == 0 && aligned16(x, ngroups) &&
+                  aligned16((const void* const*)dz, ngroups);
+#define FILLW(p) p.g = g; p.slab = workspace; p.nsplit = nsplit; p.klen = klen; \
+  for (int i = 0; i < ngroups; ++i) { p.x[i] = x[i]; p.dz[i] = dz[i]; }
+  if (in_u8) { ConvWgradP<true, 1> p; FILLW(p) e = launch_by_n(p, kkc + 1, F, nsplit, ngroups, st, "conv2d_wgrad_u8"); }
+  else if (v4) { ConvWgradP<false, 4> p; FILLW(p) e = launch_by_n(p, kkc + 1, F, nsplit, ngroups, st, "conv2d_wgrad_f32x4"); }
+  else { ConvWgradP<false, 1> p; FILLW(p) e = launch_by_n(p, kkc + 1, F, nsplit, ngroups, st, "conv2d_wgrad_f32"); }
+#undef FILLW
   if (e) return e;
   ReduceArgs ra; ra.slab = workspace; ra.nsplit = nsplit; ra.kkc = kkc; ra.F = F;
   for (int i = 0; i < ngroups; ++i) { ra.dw[i] = dw[i]; ra.db[i] = dbias[i]; }

@@ -18,9 +18,10 @@ struct GemmArgs {
   FastDiv d_seg;
 };
 
-template <bool AK_, bool BN_>
+template <bool AK_, bool BN_, int VA_, int VB_>
 struct GemmP {
   static constexpr bool A_KCONTIG = AK_, B_NCONTIG = BN_;
+  static constexpr int VA = VA_, VB = VB_;
   GemmArgs g;
   struct Ctx { const float* a; const float* b; float* c; const float* bias; };
   struct ARow { long long off; bool ok; };
@@ -45,10 +46,12 @@ struct GemmP {
     const uint32_t seg = fd_div(kk, g.d_seg), r = kk - seg * g.seglen;
     a.off = seg * g.a_ss + r * g.a_ks;
   }
-  __device__ float a_load(const Ctx& c, const ARow& r, const AK& a, float& mul, float& add) const {
+  __device__ void a_load(const Ctx& c, const ARow& r, const AK& a, VecF<VA_>& raw, float& mul, VecF<VA_>& add) const {
     const bool ok = r.ok && a.ok;
-    mul = ok ? 1.f : 0.f; add = 0.f;
-    return c.a[ok ? r.off + a.off : 0];
+    mul = ok ? 1.f : 0.f;
+#pragma unroll
+    for (int j = 0; j < VA_; ++j) add.v[j] = 0.f;
+    ld_vec<VA_>(c.a + (ok ? r.off + a.off : 0), raw);
   }
   __device__ void b_col(const Ctx&, int n, BCol& b) const { b.ok = n < g.N; b.off = b.ok ? n * g.b_ns : 0; }
   __device__ void b_k(const Ctx&, int k, int kend, BK_& b) const {
@@ -57,10 +60,10 @@ struct GemmP {
     const uint32_t seg = fd_div(kk, g.d_seg), r = kk - seg * g.seglen;
     b.off = seg * g.b_ss + r * g.b_ks;
   }
-  __device__ float b_load(const Ctx& c, const BK_& k, const BCol& n, float& mul) const {
+  __device__ void b_load(const Ctx& c, const BK_& k, const BCol& n, VecF<VB_>& raw, float& mul) const {
     const bool ok = k.ok && n.ok;
     mul = ok ? 1.f : 0.f;
-    return c.b[ok ? k.off + n.off : 0];
+    ld_vec<VB_>(c.b + (ok ? k.off + n.off : 0), raw);
   }
   __device__ void o_row(const Ctx&, int m, ORow& o) const { o.off = m * g.c_ms; }
   __device__ void o_col(const Ctx& c, int n, OCol& o) const { o.bias = c.bias ? c.bias[n] : 0.f; }
@@ -101,15 +104,29 @@ extern "C" int serl_gemm(const float* a, const float* b, float* c, const float* 
   SERL_CHECK_ARG(ns == nsplit, "gemm: nsplit %d does not tile K=%d in multiples of 16 (got %d)", nsplit, K, ns);
   hipStream_t st = (hipStream_t)stream;
   const bool big = (M >= 512 && N >= 512);
-#define GO(AK, BN)                                                                                       \
-  {                                                                                                      \
-    GemmP<AK, BN> p; p.g = g;                                                                            \
-    return big ? igemm_launch<GemmP<AK, BN>, T128x128>(p, M, N, nsplit, nbatch, st, "gemm")              \
-               : igemm_launch<GemmP<AK, BN>, T64x64>(p, M, N, nsplit, nbatch, st, "gemm");               \
+  // float4 loads along the contiguous axis when every vector of 4 is aligned, contiguous and all-or-nothing valid
+  auto m4 = [](long long v) { return (v & 3) == 0; };
+  const bool a4 = (((uintptr_t)a) & 15) == 0 && m4(a_zs) && m4(a_ss) &&
+                  (a_kcontig ? (a_ks == 1 && m4(seglen) && m4(a_ms)) : (a_ms == 1 && m4(M) && m4(a_ks)));
+  const bool b4 = (((uintptr_t)b) & 15) == 0 && m4(b_zs) && m4(b_ss) &&
+                  (b_ncontig ? (b_ns == 1 && m4(N) && m4(b_ks)) : (b_ks == 1 && m4(seglen) && m4(b_ns)));
+#define GO2(AK, BN, VA, VB)                                                                                \
+  {                                                                                                         \
+    GemmP<AK, BN, VA, VB> p; p.g = g;                                                                       \
+    return big ? igemm_launch<GemmP<AK, BN, VA, VB>, T128x128>(p, M, N, nsplit, nbatch, st, "gemm")         \
+               : igemm_launch<GemmP<AK, BN, VA, VB>, T64x64>(p, M, N, nsplit, nbatch, st, "gemm");          \
+  }
+#define GO(AK, BN)                     \
+  {                                    \
+    if (a4 && b4) GO2(AK, BN, 4, 4)    \
+    if (a4) GO2(AK, BN, 4, 1)          \
+    if (b4) GO2(AK, BN, 1, 4)          \
+    GO2(AK, BN, 1, 1)                  \
   }
   if (a_kcontig && b_ncontig) GO(true, true)
   if (a_kcontig && !b_ncontig) GO(true, false)
   if (!a_kcontig && b_ncontig) GO(false, true)
   GO(false, false)
 #undef GO
+#undef GO2
 }

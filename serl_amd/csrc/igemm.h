@@ -14,6 +14,20 @@
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int V> struct VecF { float v[V]; };
+template <int V> __device__ __forceinline__ void ld_vec(const float* p, VecF<V>& o) {
+  if constexpr (V == 4) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    o.v[0] = t.x; o.v[1] = t.y; o.v[2] = t.z; o.v[3] = t.w;
+  } else {
+    o.v[0] = p[0];
+  }
+}
+template <int V> __device__ __forceinline__ void st_vec(float* p, const VecF<V>& o) {
+  if constexpr (V == 4) *reinterpret_cast<float4*>(p) = make_float4(o.v[0], o.v[1], o.v[2], o.v[3]);
+  else p[0] = o.v[0];
+}
 #ifndef IGEMM_MIN_WAVES
 #define IGEMM_MIN_WAVES 3
 #endif
@@ -32,8 +46,10 @@ struct TileCfg {
 //   static constexpr bool A_KCONTIG, B_NCONTIG;       (which axis is contiguous in memory)
 //   bool init(Ctx&, int z) const;                     (false -> block has nothing to do)
 //   int  M(ctx), N(ctx), K(ctx);  int ksplit_len() const;
-//   void a_row(ctx, m, ARow&); void a_k(ctx, k, kend, AK&); float a_load(ctx, ARow, AK, float& mul, float& add);
-//   void b_col(ctx, n, BCol&); void b_k(ctx, k, kend, BK_&); float b_load(ctx, BK_, BCol, float& mul);
+//   static constexpr int VA, VB (1 or 4): elements per load along the contiguous axis (all-or-nothing valid);
+//   void a_row(ctx, m, ARow&); void a_k(ctx, k, kend, AK&);
+//   void a_load(ctx, ARow, AK, VecF<VA>& raw, float& mul, VecF<VA>& add);
+//   void b_col(ctx, n, BCol&); void b_k(ctx, k, kend, BK_&); void b_load(ctx, BK_, BCol, VecF<VB>& raw, float& mul);
 //   a_load / b_load return the RAW value of an unconditional load from a clamped (always valid) address; the
 //   element is raw*mul+add (mul = 0 outside the matrix).  The mask is applied when the slab is written to
 //   LDS, after the MFMAs, so the prefetch stays in flight behind them -- a select on the loaded value makes
@@ -45,7 +61,6 @@ template <class P, class T>
 __global__ __launch_bounds__(256, IGEMM_MIN_WAVES) void igemm_kernel(const P p) {
   constexpr int BM = T::BM, BN = T::BN, BK = T::BK, TM = T::TM, TN = T::TN;
   constexpr int LDA = BM + 4, LDB = BN + 4;
-  constexpr int NA = BM * BK / 256, NB = BN * BK / 256;
   __shared__ float As[2 * BK * LDA];
   __shared__ float Bs[2 * BK * LDB];
 
@@ -64,79 +79,112 @@ __global__ __launch_bounds__(256, IGEMM_MIN_WAVES) void igemm_kernel(const P p) 
   const int r = lane & 31, h = lane >> 5;
   const int wm = wid / T::WGN, wn = wid - wm * T::WGN;
 
-  // ---- per-thread load slots
+  // ---- per-thread load slots.  VA / VB = elements per load along the memory-contiguous axis (1 or 4:
+  // float4 global loads; b128 LDS stores where the LDS row runs along that axis too).
+  constexpr int VA = P::VA, VB = P::VB;
+  constexpr int A_LANES = (P::A_KCONTIG ? BK : BM) / VA;       // threads along the contiguous axis
+  constexpr int A_STEP = 256 / A_LANES;                         // rows (or k's) covered per pass
+  constexpr int A_EXT = P::A_KCONTIG ? BM : BK;                 // extent of the strided axis
+  constexpr int NA = (A_EXT + A_STEP - 1) / A_STEP;
+  constexpr int B_LANES = (P::B_NCONTIG ? BN : BK) / VB;
+  constexpr int B_STEP = 256 / B_LANES;
+  constexpr int B_EXT = P::B_NCONTIG ? BK : BN;
+  constexpr int NB = (B_EXT + B_STEP - 1) / B_STEP;
   typename P::ARow arow[P::A_KCONTIG ? NA : 1];
   typename P::BCol bcol[P::B_NCONTIG ? 1 : NB];
   int a_ml, a_kl, b_nl, b_kl;
   if constexpr (P::A_KCONTIG) {
-    a_kl = tid % BK;
-    a_ml = tid / BK;
+    a_kl = (tid % A_LANES) * VA;
+    a_ml = tid / A_LANES;
 #pragma unroll
-    for (int i = 0; i < NA; ++i) p.a_row(ctx, m0 + a_ml + i * (256 / BK), arow[i]);
+    for (int i = 0; i < NA; ++i) p.a_row(ctx, m0 + a_ml + i * A_STEP, arow[i]);
   } else {
-    a_ml = tid % BM;
-    a_kl = tid / BM;
-    // a wave covers 64 consecutive m of ONE k: make that provable so the k-side index math runs on the SALU
-    if constexpr (BM % 64 == 0) a_kl = __builtin_amdgcn_readfirstlane(a_kl);
+    a_ml = (tid % A_LANES) * VA;
+    a_kl = tid / A_LANES;
+    // a wave covers 64 consecutive lanes of ONE k: make that provable so the k-side index math runs on the SALU
+    if constexpr (A_LANES % 64 == 0) a_kl = __builtin_amdgcn_readfirstlane(a_kl);
     p.a_row(ctx, m0 + a_ml, arow[0]);
   }
   if constexpr (P::B_NCONTIG) {
-    b_nl = tid % BN;
-    b_kl = tid / BN;
-    if constexpr (BN % 64 == 0) b_kl = __builtin_amdgcn_readfirstlane(b_kl);
+    b_nl = (tid % B_LANES) * VB;
+    b_kl = tid / B_LANES;
+    if constexpr (B_LANES % 64 == 0) b_kl = __builtin_amdgcn_readfirstlane(b_kl);
     p.b_col(ctx, n0 + b_nl, bcol[0]);
   } else {
-    b_kl = tid % BK;
-    b_nl = tid / BK;
+    b_kl = (tid % B_LANES) * VB;
+    b_nl = tid / B_LANES;
 #pragma unroll
-    for (int i = 0; i < NB; ++i) p.b_col(ctx, n0 + b_nl + i * (256 / BK), bcol[i]);
+    for (int i = 0; i < NB; ++i) p.b_col(ctx, n0 + b_nl + i * B_STEP, bcol[i]);
   }
+  // when one pass already over-covers the strided axis (small tiles) the surplus threads idle (wave-uniform)
+  const bool a_on = (NA * A_STEP == A_EXT) || ((P::A_KCONTIG ? a_ml : a_kl) < A_EXT);
+  const bool b_on = (NB * B_STEP == B_EXT) || ((P::B_NCONTIG ? b_kl : b_nl) < B_EXT);
 
-  float areg[NA], breg[NB], amul[NA], aadd[NA], bmul[NB];
+  VecF<VA> areg[NA], aadd[NA];
+  VecF<VB> breg[NB];
+  float amul[NA], bmul[NB];
   auto gload = [&](int k0) {
-    if constexpr (P::A_KCONTIG) {
-      typename P::AK ak;
-      p.a_k(ctx, k0 + a_kl, kend, ak);
-#pragma unroll
-      for (int i = 0; i < NA; ++i) areg[i] = p.a_load(ctx, arow[i], ak, amul[i], aadd[i]);
-    } else {
-#pragma unroll
-      for (int i = 0; i < NA; ++i) {
+    if (a_on) {
+      if constexpr (P::A_KCONTIG) {
         typename P::AK ak;
-        p.a_k(ctx, k0 + a_kl + i * (256 / BM), kend, ak);
-        areg[i] = p.a_load(ctx, arow[0], ak, amul[i], aadd[i]);
+        p.a_k(ctx, k0 + a_kl, kend, ak);
+#pragma unroll
+        for (int i = 0; i < NA; ++i) p.a_load(ctx, arow[i], ak, areg[i], amul[i], aadd[i]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+          typename P::AK ak;
+          p.a_k(ctx, k0 + a_kl + i * A_STEP, kend, ak);
+          p.a_load(ctx, arow[0], ak, areg[i], amul[i], aadd[i]);
+        }
       }
     }
-    if constexpr (P::B_NCONTIG) {
+    if (b_on) {
+      if constexpr (P::B_NCONTIG) {
 #pragma unroll
-      for (int i = 0; i < NB; ++i) {
+        for (int i = 0; i < NB; ++i) {
+          typename P::BK_ bk;
+          p.b_k(ctx, k0 + b_kl + i * B_STEP, kend, bk);
+          p.b_load(ctx, bk, bcol[0], breg[i], bmul[i]);
+        }
+      } else {
         typename P::BK_ bk;
-        p.b_k(ctx, k0 + b_kl + i * (256 / BN), kend, bk);
-        breg[i] = p.b_load(ctx, bk, bcol[0], bmul[i]);
-      }
-    } else {
-      typename P::BK_ bk;
-      p.b_k(ctx, k0 + b_kl, kend, bk);
+        p.b_k(ctx, k0 + b_kl, kend, bk);
 #pragma unroll
-      for (int i = 0; i < NB; ++i) breg[i] = p.b_load(ctx, bk, bcol[i], bmul[i]);
+        for (int i = 0; i < NB; ++i) p.b_load(ctx, bk, bcol[i], breg[i], bmul[i]);
+      }
     }
   };
   auto lstore = [&](int buf) {
     float* As_ = As + buf * (BK * LDA);
     float* Bs_ = Bs + buf * (BK * LDB);
-    if constexpr (P::A_KCONTIG) {
+    if (a_on) {
 #pragma unroll
-      for (int i = 0; i < NA; ++i) As_[a_kl * LDA + a_ml + i * (256 / BK)] = fmaf(areg[i], amul[i], aadd[i]);
-    } else {
+      for (int i = 0; i < NA; ++i) {
+        VecF<VA> v;
 #pragma unroll
-      for (int i = 0; i < NA; ++i) As_[(a_kl + i * (256 / BM)) * LDA + a_ml] = fmaf(areg[i], amul[i], aadd[i]);
+        for (int j = 0; j < VA; ++j) v.v[j] = fmaf(areg[i].v[j], amul[i], aadd[i].v[j]);
+        if constexpr (P::A_KCONTIG) {
+#pragma unroll
+          for (int j = 0; j < VA; ++j) As_[(a_kl + j) * LDA + a_ml + i * A_STEP] = v.v[j];
+        } else {
+          st_vec<VA>(&As_[(a_kl + i * A_STEP) * LDA + a_ml], v);
+        }
+      }
     }
-    if constexpr (P::B_NCONTIG) {
+    if (b_on) {
 #pragma unroll
-      for (int i = 0; i < NB; ++i) Bs_[(b_kl + i * (256 / BN)) * LDB + b_nl] = breg[i] * bmul[i];
-    } else {
+      for (int i = 0; i < NB; ++i) {
+        VecF<VB> v;
 #pragma unroll
-      for (int i = 0; i < NB; ++i) Bs_[b_kl * LDB + b_nl + i * (256 / BK)] = breg[i] * bmul[i];
+        for (int j = 0; j < VB; ++j) v.v[j] = breg[i].v[j] * bmul[i];
+        if constexpr (P::B_NCONTIG) {
+          st_vec<VB>(&Bs_[(b_kl + i * B_STEP) * LDB + b_nl], v);
+        } else {
+#pragma unroll
+          for (int j = 0; j < VB; ++j) Bs_[(b_kl + j) * LDB + b_nl + i * B_STEP] = v.v[j];
+        }
+      }
     }
   };
 
