@@ -42,7 +42,7 @@ def fill_buffer(buf, n_transitions, seed):
 
 def cpu_baseline(seed=0):
     """CPU restatement (oracle, torch-CPU fp32 -- NOT JAX/XLA) on a bounded sample of the same workload:
-    one update() call with UTD 2 at batch 256 (2 grad-steps + the actor/temperature step)."""
+    one update() call with UTD 16 at batch 256 (16 grad-steps + the actor/temperature step), ~10-20 s."""
     import torch
     from helpers import agent_to_oracle, make_pixel_batch, pixel_spaces
     from oracle import learner as ol
@@ -50,7 +50,7 @@ def cpu_baseline(seed=0):
     obs_space, act_space = pixel_spaces(KEYS, H, W, STACK, STATE_DIM, ACT_DIM)
     agent = DrQLearner.create(seed, obs_space, act_space, pixel_keys=KEYS, **AGENT_KW)
     ostate, ocfg = agent_to_oracle(agent)
-    u = 2
+    u = 16
     batch = make_pixel_batch(np.random.default_rng(seed), BATCH * u, KEYS, H, W, STACK, STATE_DIM, ACT_DIM, packed=True)
     t0 = time.perf_counter()
     ol.drq_update(ostate, ocfg, batch, u)
