@@ -20,6 +20,14 @@ const char* serl_last_error(void);
 int serl_version(void);
 int serl_device_arch(int device, char* out, int out_len);
 
+/* Process-wide precision of every conv / GEMM entry point below; the counterpart of the reference's
+ * jax.config "jax_default_matmul_precision" (the reference never sets it: fp32 on CPU, TF32 on NVIDIA GPUs).
+ *   0 "highest": v_mfma_f32_32x32x2_f32, exact fp32 products, fp32 accumulate.
+ *   1 "bf16_3x" (default): fp32 operands split in-kernel into bf16 hi + lo, three v_mfma_f32_32x32x16_bf16
+ *     per product block (lo*hi + hi*lo + hi*hi), fp32 accumulate: <= 2^-16 relative error per product. */
+int serl_set_matmul_precision(int mode);
+int serl_get_matmul_precision(void);
+
 /* ---- convolution encoder: flax nn.Conv(VALID, bias) + ReLU, serl/networks/encoders/two_d4pg_encoder.py:30-38.
  * Grouped: group g has its own x/w/bias/y pointers (cameras x forward passes), <= 8 groups.
  * in_u8: x is uint8 and is scaled by 1/255 (correctly rounded) on load, serl/networks/pixel_multiplexer.py:27. */

@@ -22,6 +22,8 @@ PP = C.POINTER(C.c_void_p)
 _SIGS = {
     "serl_version": [],
     "serl_device_arch": [c_i, C.c_char_p, c_i],
+    "serl_set_matmul_precision": [c_i],
+    "serl_get_matmul_precision": [],
     "serl_conv2d_fwd": [c_i, PP, PP, PP, PP, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "serl_conv2d_dgrad": [c_i, PP, PP, PP, PP, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "serl_conv2d_wgrad_workspace_bytes": [c_i] * 9,
@@ -79,6 +81,10 @@ def load():
     lib.serl_last_error.argtypes = []
     lib.serl_last_error.restype = C.c_char_p
     _lib = lib
+    env = os.environ.get("SERL_AMD_MATMUL_PRECISION")
+    if env is not None:
+        from . import set_matmul_precision
+        set_matmul_precision(env)
     return lib
 
 

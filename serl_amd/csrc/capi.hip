@@ -16,6 +16,16 @@ extern "C" const char* serl_last_error(void) { return g_err; }
 
 extern "C" int serl_version(void) { return 1; }
 
+// Process-wide matmul/conv precision (the counterpart of jax.config "jax_default_matmul_precision"):
+// 0 = "highest": exact fp32 MFMA; 1 = "bf16_3x": fp32 operands split into bf16 hi+lo, 3 bf16 MFMAs, fp32 accumulate.
+static int g_matmul_precision = 1;
+extern "C" int serl_set_matmul_precision(int mode) {
+  SERL_CHECK_ARG(mode == 0 || mode == 1, "set_matmul_precision: mode must be 0 (highest) or 1 (bf16_3x)");
+  g_matmul_precision = mode;
+  return SERL_OK;
+}
+extern "C" int serl_get_matmul_precision(void) { return g_matmul_precision; }
+
 // Device query used by the Python loader to fail loudly on a non-gfx950 device.
 extern "C" int serl_device_arch(int device, char* out, int out_len) {
   hipDeviceProp_t prop;

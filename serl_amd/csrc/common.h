@@ -19,6 +19,15 @@ void serl_set_error(const char* fmt, ...);
     }                                        \
   } while (0)
 
+#define SERL_CHECK_HIP(expr, name)                                          \
+  do {                                                                      \
+    hipError_t e__ = (expr);                                                \
+    if (e__ != hipSuccess) {                                                \
+      serl_set_error("%s: %s failed: %s", name, #expr, hipGetErrorString(e__)); \
+      return SERL_ERR_HIP;                                                  \
+    }                                                                       \
+  } while (0)
+
 #define SERL_CHECK_LAUNCH(name)                                              \
   do {                                                                       \
     hipError_t e__ = hipGetLastError();                                      \

@@ -1,7 +1,7 @@
 // NHWC / HWIO VALID convolution (forward, data-gradient, weight-gradient) as implicit GEMMs
 // on the exact-fp32 MFMA pipe.  Follows flax nn.Conv as used by
 // serl/networks/encoders/two_d4pg_encoder.py:30-38 (bias, then ReLU).
-#include "igemm.h"
+#include "igemm_bf3.h"
 
 #define MAXG 8
 
@@ -288,12 +288,18 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const ReduceArgs a) {
 typedef TileCfg<128, 128, CONV_BK, 2, 2> T128x128;
 typedef TileCfg<128, 64, CONV_BK, 2, 2> T128x64;
 typedef TileCfg<128, 32, CONV_BK, 4, 1> T128x32;
+#ifndef CONV_BK3
+#define CONV_BK3 16
+#endif
+typedef TileCfg<128, 128, CONV_BK3, 2, 2> B128x128;   // bf16_3x tiles
+typedef TileCfg<128, 64, CONV_BK3, 2, 2> B128x64;
+typedef TileCfg<128, 32, CONV_BK3, 4, 1> B128x32;
 
 template <class P>
 static int launch_by_n(const P& p, int max_m, int n, int nsplit, int nz, hipStream_t st, const char* name) {
-  if (n <= 32) return igemm_launch<P, T128x32>(p, max_m, n, nsplit, nz, st, name);
-  if (n <= 64) return igemm_launch<P, T128x64>(p, max_m, n, nsplit, nz, st, name);
-  return igemm_launch<P, T128x128>(p, max_m, n, nsplit, nz, st, name);
+  if (n <= 32) return igemm_launch_prec<P, T128x32, B128x32>(p, max_m, n, nsplit, nz, st, name);
+  if (n <= 64) return igemm_launch_prec<P, T128x64, B128x64>(p, max_m, n, nsplit, nz, st, name);
+  return igemm_launch_prec<P, T128x128, B128x128>(p, max_m, n, nsplit, nz, st, name);
 }
 
 static bool aligned16(const void* const* ps, int n) {
@@ -361,7 +367,7 @@ static void wgrad_plan(const ConvGeom& g, int ngroups, int& nsplit, int& klen) {
   const int tiles = cdiv(kkc1, 128) * cdiv(g.F, bn) * ngroups;
   int want = cdiv(1024, tiles);
   if (want < 1) want = 1;
-  klen = cdiv(cdiv(Kr, want), CONV_BK) * CONV_BK;
+  klen = cdiv(cdiv(Kr, want), 32) * 32;   // multiple of both kernels' K slab
   if (klen < 64) klen = 64;
   nsplit = cdiv(Kr, klen);
 }

@@ -5,7 +5,7 @@
 //   C[z][m][n] (+)= sum_k A[z][m][k] * B[z][k][n]          z = blockIdx.z (ensemble member)
 //   A elem = a[z*a_zs + seg*a_ss + m*a_ms + r*a_ks],  B elem = b[z*b_zs + seg*b_ss + r*b_ks + n*b_ns]
 //   with k = seg*seglen + r  (segments let one GEMM reduce over (member, feature) pairs).
-#include "igemm.h"
+#include "igemm_bf3.h"
 
 struct GemmArgs {
   const float* a; const float* b; float* c; const float* bias;
@@ -113,8 +113,8 @@ extern "C" int serl_gemm(const float* a, const float* b, float* c, const float* 
 #define GO2(AK, BN, VA, VB)                                                                                \
   {                                                                                                         \
     GemmP<AK, BN, VA, VB> p; p.g = g;                                                                       \
-    return big ? igemm_launch<GemmP<AK, BN, VA, VB>, T128x128>(p, M, N, nsplit, nbatch, st, "gemm")         \
-               : igemm_launch<GemmP<AK, BN, VA, VB>, T64x64>(p, M, N, nsplit, nbatch, st, "gemm");          \
+    return big ? igemm_launch_prec<GemmP<AK, BN, VA, VB>, T128x128>(p, M, N, nsplit, nbatch, st, "gemm")         \
+               : igemm_launch_prec<GemmP<AK, BN, VA, VB>, T64x64>(p, M, N, nsplit, nbatch, st, "gemm");          \
   }
 #define GO(AK, BN)                     \
   {                                    \

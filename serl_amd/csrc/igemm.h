@@ -41,6 +41,43 @@ struct TileCfg {
   static_assert((BM_ * BK_) % 256 == 0 && (BN_ * BK_) % 256 == 0, "load mapping");
 };
 
+// ---- epilogue shared by the fp32 and the bf16x3 kernels.
+template <class P, class T>
+__device__ __forceinline__ void igemm_epilogue(const P& p, const typename P::Ctx& ctx, f32x16 (&acc)[T::TM][T::TN],
+                                               int M, int N, int m0, int n0, int wm, int wn, int r, int h, int split) {
+  constexpr int TM = T::TM, TN = T::TN;
+  // ---- epilogue: C/D map of the 32x32 tile: col = lane&31, row = (q&3) + 8*(q>>2) + 4*(lane>>5).
+  // Column context (bias) is fetched once per column; per-element auxiliary loads (ReLU mask source,
+  // accumulate target) are issued for a whole 32x32 tile before the first store so they overlap.
+  typename P::OCol ocol[TN];
+  int ncol[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    ncol[j] = n0 + wn * (TN * 32) + j * 32 + r;
+    p.o_col(ctx, ncol[j] < N ? ncol[j] : 0, ocol[j]);
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    typename P::ORow orow[16];
+    float aux[16][TN];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int m = m0 + wm * (TM * 32) + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+      p.o_row(ctx, m < M ? m : 0, orow[q]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        aux[q][j] = p.o_aux(ctx, orow[q], (m < M && ncol[j] < N) ? ncol[j] : -1, split);
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int m = m0 + wm * (TM * 32) + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        if (m < M && ncol[j] < N) p.store(ctx, orow[q], ocol[j], ncol[j], split, acc[i][j][q], aux[q][j]);
+    }
+  }
+}
+
 // Problem interface (all __device__):
 //   struct Ctx; struct ARow; struct AK; struct BCol; struct BK_;
 //   static constexpr bool A_KCONTIG, B_NCONTIG;       (which axis is contiguous in memory)
@@ -227,36 +264,7 @@ __global__ __launch_bounds__(256, IGEMM_MIN_WAVES) void igemm_kernel(const P p) 
     cur ^= 1;
   }
 
-  // ---- epilogue: C/D map of the 32x32 tile: col = lane&31, row = (q&3) + 8*(q>>2) + 4*(lane>>5).
-  // Column context (bias) is fetched once per column; per-element auxiliary loads (ReLU mask source,
-  // accumulate target) are issued for a whole 32x32 tile before the first store so they overlap.
-  typename P::OCol ocol[TN];
-  int ncol[TN];
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    ncol[j] = n0 + wn * (TN * 32) + j * 32 + r;
-    p.o_col(ctx, ncol[j] < N ? ncol[j] : 0, ocol[j]);
-  }
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    typename P::ORow orow[16];
-    float aux[16][TN];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int m = m0 + wm * (TM * 32) + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-      p.o_row(ctx, m < M ? m : 0, orow[q]);
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-        aux[q][j] = p.o_aux(ctx, orow[q], (m < M && ncol[j] < N) ? ncol[j] : -1, split);
-    }
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int m = m0 + wm * (TM * 32) + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-        if (m < M && ncol[j] < N) p.store(ctx, orow[q], ocol[j], ncol[j], split, acc[i][j][q], aux[q][j]);
-    }
-  }
+  igemm_epilogue<P, T>(p, ctx, acc, M, N, m0, n0, wm, wn, r, h, split);
 }
 
 template <class P, class T>

@@ -18,3 +18,12 @@ def dev():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+@pytest.fixture(params=["bf16_3x", "highest"])
+def prec(request):
+    """Runs the test at both matmul precisions (serl_amd.set_matmul_precision) and restores the default."""
+    import serl_amd
+    serl_amd.set_matmul_precision(request.param)
+    yield request.param
+    serl_amd.set_matmul_precision("bf16_3x")

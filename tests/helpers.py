@@ -117,8 +117,11 @@ def _leaves(tree, prefix=()):
     return [(prefix, np.asarray(tree))]
 
 
-def assert_tree_close(got, ref, rtol=None, atol=None, mean_atol=None, what="", noise_ref=None, noise_mult=4.0):
-    """noise_ref: the same quantity from the float32 oracle when `ref` is the float64 oracle; the allowed
+def assert_tree_close(got, ref, rtol=None, atol=None, mean_atol=None, what="", noise_ref=None, noise_mult=4.0,
+                      l2_rtol=None):
+    """l2_rtol: bound on ||got - ref||_2 / ||ref||_2 per leaf (robust to single ReLU-mask flips, which move one
+    gradient entry by a whole term however small the perturbation that caused the flip).
+    noise_ref: the same quantity from the float32 oracle when `ref` is the float64 oracle; the allowed
     error is then max(rtol*scale, noise_mult * |f32 oracle - f64 oracle|_max) per leaf."""
     g, r = dict(_leaves(got)), dict(_leaves(ref))
     nz = dict(_leaves(noise_ref)) if noise_ref is not None else None
@@ -133,6 +136,10 @@ def assert_tree_close(got, ref, rtol=None, atol=None, mean_atol=None, what="", n
             if nz is not None:
                 tol = max(tol, noise_mult * float(np.abs(nz[path].astype(np.float64) - b).max()))
             assert d.max() <= tol, f"{what} {'/'.join(path)}: max diff {d.max():.3e} > {tol:.3e} (scale {scale:.3e})"
+        if l2_rtol is not None:
+            nrm = float(np.sqrt((b * b).sum()))
+            e2 = float(np.sqrt((d * d).sum()))
+            assert e2 <= l2_rtol * max(nrm, 1e-12) + 1e-9, f"{what} {'/'.join(path)}: L2 rel err {e2 / max(nrm, 1e-12):.3e} > {l2_rtol:.1e}"
         if atol is not None:
             assert d.max() <= atol, f"{what} {'/'.join(path)}: max diff {d.max():.3e} > {atol:.3e}"
         if mean_atol is not None:

@@ -2,7 +2,8 @@
 (oracle/learner.py, oracle/prng.py) or a float64 numpy/torch statement of the same op.
 
 Tolerances: integer / byte work bit-exact; fp32 kernels rel 2e-5 of the output scale
-(the fp32 MFMA is an exact fmaf chain; differences are summation order only)."""
+(the fp32 MFMA is an exact fmaf chain; differences are summation order only); conv / GEMM at
+precision "bf16_3x" rel 1e-4 of the output scale (<= 2^-16 relative error per product)."""
 import math
 
 import numpy as np
@@ -52,8 +53,9 @@ def _conv_ref(x, w, b, stride):
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv_fwd_dgrad_wgrad(dev, case):
+def test_conv_fwd_dgrad_wgrad(dev, case, prec):
     ops = _ops()
+    tol = 2e-5 if prec == "highest" else 1e-4
     B, IH, IW, Cin, K, S, F, u8 = case
     rng = np.random.default_rng(1)
     G = 2
@@ -79,7 +81,7 @@ def test_conv_fwd_dgrad_wgrad(dev, case):
     for g in range(G):
         xf, w, b = refs[g]
         yref = torch.relu(_conv_ref(xf, w, b, S))
-        close(ys[g].cpu().numpy(), yref.numpy(), what=f"conv fwd g{g}")
+        close(ys[g].cpu().numpy(), yref.numpy(), rtol=tol, what=f"conv fwd g{g}")
         dz = rng.standard_normal((B, OH, OW, F)).astype(np.float32)
         dz *= (yref.numpy() > 0)                      # already ReLU-masked, as the chain delivers it
         dzs.append(dv(dz, dev))
@@ -103,19 +105,21 @@ def test_conv_fwd_dgrad_wgrad(dev, case):
         bt = torch.tensor(b, dtype=torch.float64, requires_grad=True)
         y = torch.nn.functional.conv2d(xt.permute(0, 3, 1, 2), wt.permute(3, 2, 0, 1), bt, stride=S).permute(0, 2, 3, 1)
         (y * torch.tensor(dzs[g].cpu().numpy(), dtype=torch.float64)).sum().backward()
-        close(dws[g].cpu().numpy(), wt.grad.numpy(), what=f"conv wgrad g{g}")
-        close(dbs[g].cpu().numpy(), bt.grad.numpy(), what=f"conv bias grad g{g}")
+        close(dws[g].cpu().numpy(), wt.grad.numpy(), rtol=tol, what=f"conv wgrad g{g}")
+        close(dbs[g].cpu().numpy(), bt.grad.numpy(), rtol=tol, what=f"conv bias grad g{g}")
         if not u8:
             ref_dx = xt.grad.numpy() * (xf > 0)
-            close(dxs[g].cpu().numpy(), ref_dx, what=f"conv dgrad g{g}")
+            close(dxs[g].cpu().numpy(), ref_dx, rtol=tol, what=f"conv dgrad g{g}")
 
 
 # ---------------------------------------------------------------------------------- igemm: dense
-def test_gemm_variants(dev):
+@pytest.mark.parametrize("dims", [(3, 70, 83, 45), (2, 64, 96, 128)])   # ragged (scalar loads) / aligned (float4 loads)
+def test_gemm_variants(dev, prec, dims):
     ops = _ops()
+    tol = 2e-5 if prec == "highest" else 1e-4
     rng = np.random.default_rng(2)
     st = ops.current_stream()
-    E, B, K, N = 3, 70, 83, 45
+    E, B, K, N = dims
     x = rng.standard_normal((B, K)).astype(np.float32)
     w = rng.standard_normal((E, K, N)).astype(np.float32)
     b = rng.standard_normal((E, N)).astype(np.float32)
@@ -126,7 +130,7 @@ def test_gemm_variants(dev):
              b_zs=K * N, b_ks=N, b_ns=1, c_zs=B * N, c_ms=N, bias_zs=N, relu=True, stream=st)
     ref = np.maximum(np.einsum("bk,ekn->ebn", x.astype(np.float64), w.astype(np.float64)) + b[:, None, :], 0)
     torch.cuda.synchronize()
-    close(Y.cpu().numpy(), ref, what="gemm fwd")
+    close(Y.cpu().numpy(), ref, rtol=tol, what="gemm fwd")
     # dX = sum_e dY[e] @ W[e]^T  (segmented K over (e, n)); A k-contig, B k-contig
     dy = rng.standard_normal((E, B, N)).astype(np.float32)
     DY = dv(dy, dev)
@@ -134,20 +138,20 @@ def test_gemm_variants(dev):
     ops.gemm(DY.data_ptr(), W.data_ptr(), DX.data_ptr(), None, 1, B, K, E * N, seglen=N, a_ss=B * N, a_ms=N, a_ks=1,
              b_ss=K * N, b_ks=1, b_ns=N, c_ms=K, a_kcontig=True, b_ncontig=False, stream=st)
     torch.cuda.synchronize()
-    close(DX.cpu().numpy(), np.einsum("ebn,ekn->bk", dy.astype(np.float64), w.astype(np.float64)), what="gemm dX")
+    close(DX.cpu().numpy(), np.einsum("ebn,ekn->bk", dy.astype(np.float64), w.astype(np.float64)), rtol=tol, what="gemm dX")
     # dW[e] = X^T @ dY[e]; A m-contig
     DW = torch.full((E, K, N), float("nan"), device=dev)
     ops.gemm(X.data_ptr(), DY.data_ptr(), DW.data_ptr(), None, E, K, N, B, a_zs=0, a_ms=1, a_ks=K,
              b_zs=B * N, b_ks=N, b_ns=1, c_zs=K * N, c_ms=N, a_kcontig=False, b_ncontig=True, stream=st)
     torch.cuda.synchronize()
-    close(DW.cpu().numpy(), np.einsum("bk,ebn->ekn", x.astype(np.float64), dy.astype(np.float64)), what="gemm dW")
+    close(DW.cpu().numpy(), np.einsum("bk,ebn->ekn", x.astype(np.float64), dy.astype(np.float64)), rtol=tol, what="gemm dW")
     # split-K slabs
     nsplit = 3
     SL = torch.full((nsplit, B, N), float("nan"), device=dev)
     ops.gemm(X.data_ptr(), W.data_ptr(), SL.data_ptr(), None, 1, B, N, K, a_ms=K, a_ks=1, b_ks=N, b_ns=1, c_ms=N,
              nsplit=nsplit, c_split_stride=B * N, stream=st)
     torch.cuda.synchronize()
-    close(SL.cpu().numpy().sum(0), x.astype(np.float64) @ w[0].astype(np.float64), what="gemm split-K")
+    close(SL.cpu().numpy().sum(0), x.astype(np.float64) @ w[0].astype(np.float64), rtol=tol, what="gemm split-K")
     # big-tile path (M, N >= 512) with accumulate
     M2, N2, K2 = 520, 530, 40
     a2 = rng.standard_normal((M2, K2)).astype(np.float32); b2 = rng.standard_normal((K2, N2)).astype(np.float32)
@@ -156,7 +160,7 @@ def test_gemm_variants(dev):
     ops.gemm(A2.data_ptr(), B2.data_ptr(), C2.data_ptr(), None, 1, M2, N2, K2, a_ms=K2, a_ks=1, b_ks=N2, b_ns=1,
              c_ms=N2, accumulate=True, stream=st)
     torch.cuda.synchronize()
-    close(C2.cpu().numpy(), c0 + a2.astype(np.float64) @ b2.astype(np.float64), what="gemm 128 tile")
+    close(C2.cpu().numpy(), c0 + a2.astype(np.float64) @ b2.astype(np.float64), rtol=tol, what="gemm 128 tile")
 
 
 # ---------------------------------------------------------------------------------- LN + activation

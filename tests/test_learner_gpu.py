@@ -7,6 +7,13 @@ the step is comparable (UTD 1), else 1e-3 against the float32 oracle (both sides
 through Adam's sign-like first steps), actor 5e-4 at UTD 1 and 1e-2 after several critic steps (its
 Q-gradient is a mean over the ensemble that nearly cancels at init, so it amplifies that drift);
 augmentation and indices bit-exact.
+The tight per-entry gradient bounds hold at matmul precision "highest" (exact fp32 MFMA).  At the default
+"bf16_3x" (each product accurate to ~2^-17) a pre-activation within ~1e-5 of zero can land on the other side
+of a ReLU, which moves single gradient entries by a whole term; gradients are then bounded per leaf in relative
+L2 norm (1e-2; 3e-2 after several Adam steps) and by 5e-2 of the leaf's max magnitude.  Losses / Q / entropy / temperature at "bf16_3x": rel 1e-3
+for every update() call with one critic step, started from the product's own state (the oracle is re-synchronised
+before each call), rel 5e-3 when the call holds several Adam steps (UTD > 1): Adam's sign-like first steps turn a
+1e-6 gradient difference into a +-lr parameter difference, so two correct implementations separate at that rate.
 Parameters after Adam are compared loosely (Adam's first steps are ~sign(g): a gradient that is noise
 around 0 may move a weight by +-lr in either implementation)."""
 import numpy as np
@@ -26,8 +33,20 @@ def _check_params(agent, ostate, lr, steps):
         assert_tree_close(got, ref, atol=2.5 * lr * steps, mean_atol=2e-5, what=f"{name} params")
 
 
+def _check_grads(agent, name, ref64, ref32, prec, rtol, noise_ref=None):
+    got = agent._shared[name].numpy_tree()
+    if prec == "highest":
+        if noise_ref is not None:
+            assert_tree_close(got, ref64, rtol=rtol, what=name, noise_ref=noise_ref)
+        else:
+            assert_tree_close(got, ref32, rtol=rtol, what=name)
+    else:
+        ref = ref64 if noise_ref is not None else ref32
+        assert_tree_close(got, ref, rtol=5e-2, l2_rtol=1e-2 if noise_ref is not None else 3e-2, what=name)
+
+
 @pytest.mark.parametrize("cfgname", ["sac_c1", "rlpd_u1", "rlpd_c2", "redq_m3"])
-def test_state_learner_matches_oracle(dev, cfgname):
+def test_state_learner_matches_oracle(dev, cfgname, prec):
     from oracle import learner as ol
     from serl_amd.agents import SACLearner
     obs_space, act_space = state_spaces(17, 6)
@@ -46,25 +65,26 @@ def test_state_learner_matches_oracle(dev, cfgname):
     agent = SACLearner.create(42, obs_space, act_space, **kw)
     ostate, ocfg = agent_to_oracle(agent)
     rng = np.random.default_rng(0)
+    info_tol = 1e-3 if (prec == "highest" or U == 1) else 5e-3
     for it in range(3):
         batch = make_state_batch(rng, B * U, 17, 6)
         collect, c64 = [], []
+        if prec != "highest":
+            ostate, _ = agent_to_oracle(agent)                                        # per-call parity (see module doc)
         ol.sac_update(ostate, ocfg, batch, U, dtype=torch.float64, collect=c64)      # float64 gradients
         ostate, oinfo = ol.sac_update(ostate, ocfg, batch, U, collect=collect)
         agent, info = agent.update(batch, U)
-        assert_info_close(info, oinfo, rtol=1e-3)
+        assert_info_close(info, oinfo, rtol=info_tol)
         assert np.array_equal(agent.rng, ostate["rng"])
         if U == 1:   # with U > 1 the f64 run's parameters drift from the f32 run's before the last step
-            assert_tree_close(agent._shared["critic_grads"].numpy_tree(), c64[-2]["grads"], rtol=2e-4,
-                              what="critic grads", noise_ref=collect[-2]["grads"])
-            assert_tree_close(agent._shared["actor_grads"].numpy_tree(), c64[-1]["grads"], rtol=5e-4,
-                              what="actor grads", noise_ref=collect[-1]["grads"])
+            _check_grads(agent, "critic_grads", c64[-2]["grads"], None, prec, 2e-4, noise_ref=collect[-2]["grads"])
+            _check_grads(agent, "actor_grads", c64[-1]["grads"], None, prec, 5e-4, noise_ref=collect[-1]["grads"])
         else:
-            assert_tree_close(agent._shared["critic_grads"].numpy_tree(), collect[-2]["grads"], rtol=1e-3,
-                              what="critic grads")
-            assert_tree_close(agent._shared["actor_grads"].numpy_tree(), collect[-1]["grads"], rtol=1e-2,
-                              what="actor grads")
+            _check_grads(agent, "critic_grads", None, collect[-2]["grads"], prec, 1e-3)
+            _check_grads(agent, "actor_grads", None, collect[-1]["grads"], prec, 1e-2)
     _check_params(agent, ostate, 3e-4, 3 * U)
+    if prec != "highest":
+        ostate, _ = agent_to_oracle(agent)
     # acting
     ob = rng.standard_normal(17).astype(np.float32)
     a, agent2 = agent.sample_actions(ob)
@@ -76,7 +96,7 @@ def test_state_learner_matches_oracle(dev, cfgname):
 
 
 @pytest.mark.parametrize("variant", ["e1_packed", "e1_packed_utd2", "e0_unpacked_small"])
-def test_drq_learner_matches_oracle(dev, variant):
+def test_drq_learner_matches_oracle(dev, variant, prec):
     from oracle import learner as ol
     from serl_amd.agents import DrQLearner
     if variant.startswith("e1_packed"):   # BASELINE config 3 shapes, RLPD settings, tiny batch for the CPU oracle
@@ -100,7 +120,9 @@ def test_drq_learner_matches_oracle(dev, variant):
             osync, _ = agent_to_oracle(agent)
             ol.drq_update(osync, ocfg, batch, U, dtype=torch.float64, collect=c64)
             ol.drq_update(osync, ocfg, batch, U, collect=csync)
-        ostate, oinfo = ol.drq_update(ostate, ocfg, batch, U, collect=collect)     # free-running trajectory
+        if prec != "highest":
+            ostate, _ = agent_to_oracle(agent)                                     # per-call parity (see module doc)
+        ostate, oinfo = ol.drq_update(ostate, ocfg, batch, U, collect=collect)     # free-running trajectory at "highest"
         agent, info = agent.update(batch, U, pixel_keys=keys)
         # augmentation bit-exact (uint8)
         ws = agent._ws(B)
@@ -108,13 +130,11 @@ def test_drq_learner_matches_oracle(dev, variant):
             for cam in keys:
                 got = ws.tensor(f"aug_{side}_{cam}", (B * U, H, W, 3 * S), torch.uint8).cpu().numpy()
                 assert np.array_equal(got.reshape(B * U, H, W, 3, S), collect[0][okey][cam]), f"aug {side} {cam}"
-        assert_info_close(info, oinfo, rtol=1e-3)
+        assert_info_close(info, oinfo, rtol=1e-3 if (prec == "highest" or U == 1) else 5e-3)
         assert np.array_equal(agent.rng, ostate["rng"])
         if U == 1:
-            assert_tree_close(agent._shared["critic_grads"].numpy_tree(), c64[-2]["grads"], rtol=3e-4,
-                              what="critic grads", noise_ref=csync[-2]["grads"])
-            assert_tree_close(agent._shared["actor_grads"].numpy_tree(), c64[-1]["grads"], rtol=5e-4,
-                              what="actor grads", noise_ref=csync[-1]["grads"])
+            _check_grads(agent, "critic_grads", c64[-2]["grads"], None, prec, 3e-4, noise_ref=csync[-2]["grads"])
+            _check_grads(agent, "actor_grads", c64[-1]["grads"], None, prec, 5e-4, noise_ref=csync[-1]["grads"])
     _check_params(agent, ostate, 3e-4, 2 * U)
     ob = {k: rng.integers(0, 256, size=(H, W, 3, S), dtype=np.uint8) for k in keys}
     ob["state"] = rng.standard_normal(19).astype(np.float32)

@@ -9,12 +9,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from serl_amd import ops  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+ONLY = os.environ.get("BENCH_ONLY", "")        # e.g. "conv3 fwd,conv2 dgrad": run only these launches
+NITER = int(os.environ.get("BENCH_N", "20"))
 dev = torch.device("cuda")
 LAYERS = [(128, 9, 32), (63, 32, 64), (31, 64, 128), (15, 128, 256)]   # IH, C, F  (3x3, stride 2)
 st = ops.current_stream()
 
 
-def timeit(fn, n=20):
+def timeit(fn, n=NITER):
     fn(); torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
@@ -30,6 +32,8 @@ for li, (IH, C, F) in enumerate(LAYERS):
     flop1 = 2.0 * B * OH * OH * F * 9 * C
     for G, what in ((6, "fwd"), (2, "wgrad"), (2, "dgrad")):
         if what == "dgrad" and li == 0:
+            continue
+        if ONLY and f"conv{li + 1} {what}" not in ONLY.split(","):
             continue
         if li == 0:
             xs = [torch.randint(0, 256, (B, IH, IH, C), dtype=torch.uint8, device=dev) for _ in range(G)]
