@@ -44,10 +44,32 @@ int serl_conv2d_wgrad(int ngroups, const void* const* x, const float* const* dz,
                       float* const* dbias, float* workspace, long long workspace_bytes, int in_u8, int B, int IH,
                       int IW, int C, int KH, int KW, int stride, int F, void* stream);
 
+/* ---- the same convolutions on S-format tensors (precision "bf16_3x" without any in-kernel conversion).
+ * S format of a [rows][cols] fp32 tensor, cols % 8 == 0: unsigned short[rows][2][cols]; per row the cols bf16 "hi"
+ * values (bf16_rn(x)) then the cols bf16 "lo" values (bf16_rn(x - hi)); 4 bytes per element like fp32, 16-byte
+ * aligned.  Activations (NHWC: rows = pixels, cols = channels) and their gradients stay in this format between
+ * layers; the first layer reads uint8 pixels (KW*C <= 32).  serl_convs_prep_weights re-lays an HWIO fp32 kernel
+ * out as wf (forward operand, serl_convs_weight_bytes bytes) and wd (data-gradient operand, 4*KH*KW*C*F bytes;
+ * may be NULL).  No counterpart in the reference: XLA picks its own internal layouts. */
+long long serl_convs_weight_bytes(int in_u8, int KH, int KW, int C, int F);
+int serl_split_f32(const float* in, void* out, long long rows, int cols, void* stream);
+int serl_merge_split(const void* in, float* out, long long rows, int cols, void* stream);
+int serl_convs_prep_weights(int ngroups, const float* const* w, void* const* wf, void* const* wd, int in_u8, int KH,
+                            int KW, int C, int F, void* stream);
+int serl_convs_fwd(int ngroups, const void* const* x, const void* const* wf, const float* const* bias, void* const* y,
+                   int in_u8, int B, int IH, int IW, int C, int KH, int KW, int stride, int F, int relu, void* stream);
+int serl_convs_dgrad(int ngroups, const void* const* dz, const void* const* wd, const void* const* xact,
+                     void* const* dx, int B, int IH, int IW, int C, int KH, int KW, int stride, int F, void* stream);
+int serl_convs_wgrad(int ngroups, const void* const* x, const void* const* dz, float* const* dw, float* const* dbias,
+                     float* workspace, long long workspace_bytes, int in_u8, int B, int IH, int IW, int C, int KH,
+                     int KW, int stride, int F, void* stream);
+
 /* ---- SpatialLearnedEmbeddings, serl/networks/spatial.py:13-27 (F must be 8) */
-int serl_sle_fwd(const float* feat, const float* ker, float* out, int ldo, int B, int HW, int C, int F, void* stream);
-int serl_sle_bwd(const float* dout, int ldo, const float* ker, const float* feat, float* dfeat, float* dker, int B,
-                 int HW, int C, int F, void* stream);
+int serl_sle_fwd(const void* feat, const float* ker, float* out, int ldo, int B, int HW, int C, int F, int feat_split,
+                 void* stream);
+int serl_sle_bwd(const float* dout, int ldo, const float* ker, const void* feat, void* dfeat, float* dker, int B,
+                 int HW, int C, int F, int feat_split, void* stream);
+/* feat_split != 0: feat / dfeat are S-format tensors (below) instead of fp32. */
 
 /* ---- batched / segmented dense GEMM: nn.Dense of serl/networks/mlp.py:21-25, pixel_multiplexer.py:34,39, the
  * nn.vmap ensemble of serl/networks/ensemble.py:14-22 (nbatch = members) and their backward products.

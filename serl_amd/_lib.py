@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libserl_hip.so")
+LIB_PATH = os.environ.get("SERL_AMD_LIB") or os.path.join(_HERE, "csrc", "libserl_hip.so")   # override: kernel experiments only
 
 c_p = C.c_void_p
 c_i = C.c_int
@@ -43,8 +43,15 @@ _SIGS = {
     "serl_actor_loss": [c_p, c_i, c_i, c_p, c_p, c_p, c_p],
     "serl_adam_polyak": [c_p, c_p, c_p, c_p, c_p, c_ll, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p],
     "serl_temperature_update": [c_p, c_p, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p, c_p],
-    "serl_sle_fwd": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
-    "serl_sle_bwd": [c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    "serl_sle_fwd": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
+    "serl_sle_bwd": [c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
+    "serl_convs_weight_bytes": [c_i] * 5,
+    "serl_split_f32": [c_p, c_p, c_ll, c_i, c_p],
+    "serl_merge_split": [c_p, c_p, c_ll, c_i, c_p],
+    "serl_convs_prep_weights": [c_i, PP, PP, PP, c_i, c_i, c_i, c_i, c_i, c_p],
+    "serl_convs_fwd": [c_i, PP, PP, PP, PP, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
+    "serl_convs_dgrad": [c_i, PP, PP, PP, PP, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
+    "serl_convs_wgrad": [c_i, PP, PP, PP, PP, c_p, c_ll, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "serl_gather_crop_frames": [c_p, c_ll, c_p, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
     "serl_gather_crop_packed": [c_p, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
     "serl_gather_window": [c_p, c_ll, c_p, c_p, c_i, c_i, c_i, c_p],
@@ -53,7 +60,7 @@ _SIGS = {
     "serl_prng_bits": [c_u, c_u, c_i, c_p],
     "serl_prng_choice": [c_u, c_u, c_i, c_i, c_p],
 }
-_RESTYPE = {"serl_conv2d_wgrad_workspace_bytes": c_ll}
+_RESTYPE = {"serl_conv2d_wgrad_workspace_bytes": c_ll, "serl_convs_weight_bytes": c_ll}
 
 EXPORTS = tuple(_SIGS) + ("serl_last_error",)
 

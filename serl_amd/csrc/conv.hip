@@ -3,25 +3,7 @@
 // serl/networks/encoders/two_d4pg_encoder.py:30-38 (bias, then ReLU).
 #include "igemm_bf3.h"
 
-#define MAXG 8
-
-struct ConvGeom {
-  int B, IH, IW, C, OH, OW, F, KH, KW, S;
-  FastDiv d_ohow, d_ow, d_kwc;
-};
-
-static int make_geom(ConvGeom& g, int B, int IH, int IW, int C, int KH, int KW, int S, int F) {
-  SERL_CHECK_ARG(B > 0 && IH >= KH && IW >= KW && C > 0 && F > 0 && S > 0 && KH > 0 && KW > 0, "conv: bad geometry");
-  g.B = B; g.IH = IH; g.IW = IW; g.C = C; g.KH = KH; g.KW = KW; g.S = S; g.F = F;
-  g.OH = (IH - KH) / S + 1;
-  g.OW = (IW - KW) / S + 1;
-  SERL_CHECK_ARG((long long)B * IH * IW * C < (1ll << 31) && (long long)B * g.OH * g.OW * F < (1ll << 31),
-                 "conv: tensor exceeds 2^31 elements");
-  g.d_ohow = make_fastdiv(g.OH * g.OW);
-  g.d_ow = make_fastdiv(g.OW);
-  g.d_kwc = make_fastdiv(KW * C);
-  return SERL_OK;
-}
+#include "conv_geom.h"
 
 // x/255 correctly rounded (reference: pixel_multiplexer.py:27 divides in float32).
 __device__ __forceinline__ float u8_to_unit(unsigned char v) {
@@ -257,30 +239,6 @@ struct ConvWgradP {
   }
 };
 
-// out[g][e] = sum_s slab[g][s][e]; rows < KKC go to dW, the last row to dbias. 64 elements x 4 s-lanes.
-struct ReduceArgs {
-  const float* slab; float* dw[MAXG]; float* db[MAXG];
-  int nsplit, kkc, F;
-};
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const ReduceArgs a) {
-  __shared__ float part[4][64];
-  const int gi = blockIdx.y;
-  const int nel = (a.kkc + 1) * a.F;
-  const int el = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int sl = threadIdx.x >> 6;
-  const float* base = a.slab + (size_t)gi * a.nsplit * (size_t)nel;
-  float s = 0.f;
-  if (el < nel)
-    for (int k = sl; k < a.nsplit; k += 4) s += base[(size_t)k * nel + el];
-  part[sl][threadIdx.x & 63] = s;
-  __syncthreads();
-  if (sl == 0 && el < nel) {
-    const float v = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
-    if (el < a.kkc * a.F) a.dw[gi][el] = v;
-    else a.db[gi][el - a.kkc * a.F] = v;
-  }
-}
-
 // ------------------------------------------------------------------------------ host API
 #ifndef CONV_BK
 #define CONV_BK 16
@@ -358,18 +316,6 @@ extern "C" int serl_conv2d_dgrad(int ngroups, const float* const* dz, const floa
   const bool v4 = F % 4 == 0 && aligned16((const void* const*)dz, ngroups) && aligned16((const void* const*)w, ngroups);
   if (v4) return dgrad_go<4>(g, ngroups, dz, w, xact, dx, stride, (hipStream_t)stream);
   return dgrad_go<1>(g, ngroups, dz, w, xact, dx, stride, (hipStream_t)stream);
-}
-
-static void wgrad_plan(const ConvGeom& g, int ngroups, int& nsplit, int& klen) {
-  const int Kr = g.B * g.OH * g.OW;
-  const int kkc1 = g.KH * g.KW * g.C + 1;
-  const int bn = g.F <= 32 ? 32 : (g.F <= 64 ? 64 : 128);
-  const int tiles = cdiv(kkc1, 128) * cdiv(g.F, bn) * ngroups;
-  int want = cdiv(1024, tiles);
-  if (want < 1) want = 1;
-  klen = cdiv(cdiv(Kr, want), 32) * 32;   // multiple of both kernels' K slab
-  if (klen < 64) klen = 64;
-  nsplit = cdiv(Kr, klen);
 }
 
 extern "C" long long serl_conv2d_wgrad_workspace_bytes(int ngroups, int B, int IH, int IW, int C, int KH, int KW,

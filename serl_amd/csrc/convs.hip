@@ -1,0 +1,477 @@
+// The conv encoder at precision "bf16_3x" with S-format tensors (sgemm.h): activations, activation
+// gradients and re-laid-out weights live in HBM as bf16 hi / lo planes, so forward, data-gradient and
+// weight-gradient are pure bf16-MFMA implicit GEMMs.  Same math as conv.hip (flax nn.Conv VALID + bias +
+// ReLU, serl/networks/encoders/two_d4pg_encoder.py:30-38) and the same split-K / fixed-order reduction for
+// the weight gradient.  The first layer reads the uint8 pixels directly: integers 0..255 are exact in
+// bf16, so its A operand has no lo plane and 1/255 (pixel_multiplexer.py:27) is applied to the accumulator.
+#include "conv_geom.h"
+#include "sgemm.h"
+
+typedef unsigned short ushort_t;
+
+static __device__ unsigned long long g_ones_u8 = 1ull;   // bytes (1, 0, 0, 0, 0, 0, 0, 0)
+
+__device__ __forceinline__ const char* zero_page() { return reinterpret_cast<const char*>(g_zero_page); }
+
+__device__ __forceinline__ void split1(float v, ushort_t& hi, ushort_t& lo) {
+  uint32_t h, l;
+  split_pair(v, 0.f, h, l);
+  hi = (ushort_t)h; lo = (ushort_t)l;
+}
+
+// ------------------------------------------------------------------------------ forward
+// A: KC, rows = output pixels, k = (ky, kx, c)          [uint8: k' = ky*32 + kx*C + c, KW*C <= 32]
+// B: KC, rows = output channels, from wf = S-format [F][2][Kp] (k order as A)
+template <bool U8>
+struct ConvFwdS {
+  static constexpr bool A_KC = true, B_KC = true, A_LO = !U8, B_LO = true, A_U8 = U8;
+  ConvGeom g;
+  int Kp;
+  float scale;                      // 1/255 for uint8 input, else 1
+  FastDiv d_c, d_kw;
+  const void* x[MAXG];
+  const ushort_t* wf[MAXG];
+  const float* bias[MAXG];
+  ushort_t* y[MAXG];
+  int relu;
+  struct Ctx { const char* x; const ushort_t* wf; const float* bias; ushort_t* y; };
+  struct ARow { uint32_t base; bool ok; };
+  struct AK { uint32_t off; int sh; bool ok; };
+  struct BRow { uint32_t base; bool ok; };
+  struct BK_ { uint32_t off; bool ok; };
+  struct ORow { uint32_t base; };
+  struct OCol { float bias; };
+  __device__ bool init(Ctx& c, int z) const { c.x = (const char*)x[z]; c.wf = wf[z]; c.bias = bias[z]; c.y = y[z]; return true; }
+  __device__ int M(const Ctx&) const { return g.B * g.OH * g.OW; }
+  __device__ int N(const Ctx&) const { return g.F; }
+  __device__ int K(const Ctx&) const { return Kp; }
+  __device__ int ksplit_len() const { return 1 << 30; }
+  __device__ void a_row(const Ctx& c, int m, ARow& r) const {
+    r.ok = m < M(c);
+    const uint32_t mm = r.ok ? m : 0;
+    const uint32_t b = fd_div(mm, g.d_ohow), rem = mm - b * (g.OH * g.OW);
+    const uint32_t oy = fd_div(rem, g.d_ow), ox = rem - oy * g.OW;
+    const uint32_t pix = (b * g.IH + oy * g.S) * g.IW + ox * g.S;
+    r.base = U8 ? pix * g.C : pix * 2 * g.C;
+  }
+  __device__ void a_k(const Ctx&, int k, int kend, AK& a) const {
+    a.ok = k < kend;
+    a.sh = 0;
+    const uint32_t kk = a.ok ? k : 0;
+    if constexpr (U8) {
+      const int ky = kk >> 5, j0 = kk & 31, run = g.KW * g.C;
+      const int over = j0 + 8 - run;                 // bytes of this chunk past the (kx, c) run of row ky
+      a.ok = a.ok && j0 < run;
+      const int back = over > 0 ? over : 0;          // read the 8 bytes that END at the run's end and shift
+      a.off = ky * (g.IW * g.C) + j0 - back;
+      a.sh = 8 * back;
+    } else {
+      const uint32_t tap = fd_div(kk, d_c), c0 = kk - tap * g.C;
+      const uint32_t ky = fd_div(tap, d_kw), kx = tap - ky * g.KW;
+      a.off = (ky * g.IW + kx) * 2 * g.C + c0;
+    }
+  }
+  __device__ void a_ptr(const Ctx& c, const ARow& r, const AK& a, const char*& hi, const char*& lo, int& sh) const {
+    const bool ok = r.ok && a.ok;
+    hi = ok ? c.x + (r.base + a.off) : zero_page();
+    lo = hi;
+    sh = ok ? a.sh : 0;
+  }
+  __device__ void a_ptr(const Ctx& c, const ARow& r, const AK& a, const char*& hi, const char*& lo) const {
+    const bool ok = r.ok && a.ok;
+    hi = ok ? c.x + 2ull * (r.base + a.off) : zero_page();
+    lo = hi + 2 * g.C;
+  }
+  __device__ void b_row(const Ctx&, int n, BRow& b) const { b.ok = n < g.F; b.base = b.ok ? (uint32_t)n * 2 * Kp : 0; }
+  __device__ void b_k(const Ctx&, int k, int kend, BK_& b) const { b.ok = k < kend; b.off = b.ok ? k : 0; }
+  __device__ void b_ptr(const Ctx& c, const BRow& n, const BK_& k, const char*& hi, const char*& lo) const {
+    const bool ok = n.ok && k.ok;
+    hi = ok ? (const char*)(c.wf + n.base + k.off) : zero_page();
+    lo = hi + 2 * Kp;
+  }
+  __device__ void o_col(const Ctx& c, int n, OCol& o) const { o.bias = c.bias[n]; }
+  __device__ void o_row(const Ctx&, int m, ORow& o) const { o.base = (uint32_t)m * 2 * g.F; }
+  __device__ float o_aux(const Ctx&, const ORow&, int, int) const { return 0.f; }
+  __device__ void store(const Ctx& c, const ORow& o, const OCol& oc, int n, int, float v, float) const {
+    v = fmaf(v, scale, oc.bias);
+    if (relu) v = fmaxf(v, 0.f);
+    ushort_t h, l;
+    split1(v, h, l);
+    c.y[o.base + n] = h;
+    c.y[o.base + g.F + n] = l;
+  }
+};
+
+// ------------------------------------------------------------------------------ dgrad
+// per parity class of input pixels (conv.hip): A: KC, rows = input pixels of the class, k = (tap, f) from dz (S);
+// B: KC, rows = input channels, from wd = S-format of the HWIO kernel viewed as [(ky,kx,c)][2][F].
+struct ConvDgradS {
+  static constexpr bool A_KC = true, B_KC = true, A_LO = true, B_LO = true, A_U8 = false;
+  ConvGeom g;
+  int G;
+  const ushort_t* dz[MAXG];
+  const ushort_t* wd[MAXG];
+  const ushort_t* xact[MAXG];
+  ushort_t* dx[MAXG];
+  struct Cls { int py, px, IHc, IWc, TY, TX; FastDiv d_hw, d_w, d_tx; };
+  Cls cls[4];
+  FastDiv d_f_;
+  struct Ctx {
+    const ushort_t* dz; const ushort_t* wd; const ushort_t* xact; ushort_t* dx;
+    int py, px, IHc, IWc, TY, TX;
+    FastDiv d_hw, d_w, d_f, d_tx;
+  };
+  struct ARow { int pix, iyp, ixp; bool ok; };
+  struct AK { int dpix, jy, jx, f0; bool ok; };
+  struct BRow { uint32_t c; bool ok; };
+  struct BK_ { uint32_t off; bool ok; };
+  struct ORow { uint32_t base; };
+  struct OCol {};
+  __device__ bool init(Ctx& c, int z) const {
+    const int ci = z / G, gi = z - ci * G;
+    c.dz = dz[gi]; c.wd = wd[gi]; c.xact = xact[gi]; c.dx = dx[gi];
+    const Cls& k = cls[ci];
+    c.py = k.py; c.px = k.px; c.IHc = k.IHc; c.IWc = k.IWc; c.TY = k.TY; c.TX = k.TX;
+    c.d_hw = k.d_hw; c.d_w = k.d_w; c.d_tx = k.d_tx; c.d_f = d_f_;
+    return c.IHc > 0 && c.IWc > 0;
+  }
+  __device__ int M(const Ctx& c) const { return g.B * c.IHc * c.IWc; }
+  __device__ int N(const Ctx&) const { return g.C; }
+  __device__ int K(const Ctx& c) const { return c.TY * c.TX * g.F; }
+  __device__ int ksplit_len() const { return 1 << 30; }
+  __device__ void a_row(const Ctx& c, int m, ARow& r) const {
+    r.ok = m < M(c);
+    const uint32_t mm = r.ok ? m : 0;
+    const uint32_t b = fd_div(mm, c.d_hw), rem = mm - b * (c.IHc * c.IWc);
+    const uint32_t iyp = fd_div(rem, c.d_w), ixp = rem - iyp * c.IWc;
+    r.iyp = iyp; r.ixp = ixp;
+    r.pix = (int)((b * g.OH + iyp) * g.OW + ixp);
+  }
+  __device__ void a_k(const Ctx& c, int k, int kend, AK& a) const {
+    a.ok = k < kend;
+    const uint32_t kk = a.ok ? k : 0;
+    const uint32_t t = fd_div(kk, c.d_f), f0 = kk - t * g.F;
+    const uint32_t jy = fd_div(t, c.d_tx), jx = t - jy * c.TX;
+    a.jy = jy; a.jx = jx; a.f0 = f0;
+    a.dpix = (int)(jy * g.OW + jx);
+  }
+  __device__ void a_ptr(const Ctx& c, const ARow& r, const AK& a, const char*& hi, const char*& lo) const {
+    const int oy = r.iyp - a.jy, ox = r.ixp - a.jx;
+    const bool ok = r.ok && a.ok && oy >= 0 && oy < g.OH && ox >= 0 && ox < g.OW;
+    const uint32_t off = (uint32_t)(r.pix - a.dpix) * 2 * g.F + a.f0;
+    hi = ok ? (const char*)(c.dz + off) : zero_page();
+    lo = hi + 2 * g.F;
+  }
+  __device__ void b_row(const Ctx&, int n, BRow& b) const { b.ok = n < g.C; b.c = b.ok ? n : 0; }
+  __device__ void b_k(const Ctx& c, int k, int kend, BK_& b) const {
+    b.ok = k < kend;
+    const uint32_t kk = b.ok ? k : 0;
+    const uint32_t t = fd_div(kk, c.d_f), f0 = kk - t * g.F;
+    const uint32_t jy = fd_div(t, c.d_tx), jx = t - jy * c.TX;
+    const uint32_t ky = c.py + g.S * jy, kx = c.px + g.S * jx;
+    b.off = ((ky * g.KW + kx) * g.C) * 2 * g.F + f0;
+  }
+  __device__ void b_ptr(const Ctx& c, const BRow& n, const BK_& k, const char*& hi, const char*& lo) const {
+    const bool ok = n.ok && k.ok;
+    hi = ok ? (const char*)(c.wd + k.off + n.c * 2 * g.F) : zero_page();
+    lo = hi + 2 * g.F;
+  }
+  __device__ void o_row(const Ctx& c, int m, ORow& o) const {
+    const uint32_t b = fd_div((uint32_t)m, c.d_hw), rem = m - b * (c.IHc * c.IWc);
+    const uint32_t iyp = fd_div(rem, c.d_w), ixp = rem - iyp * c.IWc;
+    o.base = ((b * g.IH + iyp * g.S + c.py) * g.IW + ixp * g.S + c.px) * 2 * g.C;
+  }
+  __device__ void o_col(const Ctx&, int, OCol&) const {}
+  __device__ float o_aux(const Ctx& c, const ORow& o, int n, int) const {
+    if (c.xact == nullptr) return 1.f;
+    return (c.xact[n >= 0 ? o.base + n : 0] & 0x7fffu) ? 1.f : 0.f;     // hi plane of a post-ReLU activation
+  }
+  __device__ void store(const Ctx& c, const ORow& o, const OCol&, int n, int, float v, float aux) const {
+    ushort_t h, l;
+    split1(aux > 0.f ? v : 0.f, h, l);
+    c.dx[o.base + n] = h;
+    c.dx[o.base + g.C + n] = l;
+  }
+};
+
+// ------------------------------------------------------------------------------ wgrad
+// A: RC, rows = (ky, kx, c) [+ an all-ones row -> dbias], k = output pixels, from x (S or uint8);
+// B: RC, rows = output channels, k = output pixels, from dz (S).  Output: fp32 slabs as in conv.hip.
+template <bool U8>
+struct ConvWgradS {
+  static constexpr bool A_KC = false, B_KC = false, A_LO = !U8, B_LO = true, A_U8 = U8;
+  ConvGeom g;
+  FastDiv d_c, d_kw;
+  const void* x[MAXG];
+  const ushort_t* dz[MAXG];
+  float* slab;
+  int nsplit, klen, Mp, kkc;      // Mp: rows of the virtual A incl. the ones row; kkc = KH*KW*C
+  float scale;
+  struct Ctx { const char* x; const ushort_t* dz; float* slab; };
+  struct ARow { uint32_t off; int sh, kind; };      // kind: 0 zero, 1 data, 2 ones
+  struct AK { uint32_t base; bool ok; };
+  struct BRow { uint32_t n; bool ok; };
+  struct BK_ { uint32_t off; bool ok; };
+  struct ORow { int base; };
+  struct OCol {};
+  __device__ bool init(Ctx& c, int z) const {
+    c.x = (const char*)x[z]; c.dz = dz[z];
+    c.slab = slab + (size_t)z * nsplit * (size_t)((kkc + 1) * g.F);
+    return true;
+  }
+  __device__ int M(const Ctx&) const { return Mp; }
+  __device__ int N(const Ctx&) const { return g.F; }
+  __device__ int K(const Ctx&) const { return g.B * g.OH * g.OW; }
+  __device__ int ksplit_len() const { return klen; }
+  __device__ void a_row(const Ctx&, int m, ARow& r) const {
+    r.sh = 0; r.off = 0;
+    if constexpr (U8) {
+      const int ky = m >> 5, j0 = m & 31, run = g.KW * g.C;
+      r.kind = (ky < g.KH && j0 < run) ? 1 : (m == g.KH * 32 ? 2 : 0);
+      if (r.kind == 1) {
+        const int over = j0 + 8 - run, back = over > 0 ? over : 0;
+        r.off = ky * (g.IW * g.C) + j0 - back;
+        r.sh = 8 * back;
+      }
+    } else {
+      r.kind = m < kkc ? 1 : (m == kkc ? 2 : 0);
+      if (r.kind == 1) {
+        const uint32_t tap = fd_div((uint32_t)m, d_c), c0 = m - tap * g.C;
+        const uint32_t ky = fd_div(tap, d_kw), kx = tap - ky * g.KW;
+        r.off = (ky * g.IW + kx) * 2 * g.C + c0;
+      }
+    }
+  }
+  __device__ void a_k(const Ctx&, int k, int kend, AK& a) const {
+    a.ok = k < kend;
+    const uint32_t mm = a.ok ? k : 0;
+    const uint32_t b = fd_div(mm, g.d_ohow), rem = mm - b * (g.OH * g.OW);
+    const uint32_t oy = fd_div(rem, g.d_ow), ox = rem - oy * g.OW;
+    const uint32_t pix = (b * g.IH + oy * g.S) * g.IW + ox * g.S;
+    a.base = U8 ? pix * g.C : pix * 2 * g.C;
+  }
+  __device__ void a_ptr(const Ctx& c, const ARow& r, const AK& a, const char*& hi, const char*& lo, int& sh) const {
+    const bool data = a.ok && r.kind == 1, ones = a.ok && r.kind == 2;
+    hi = data ? c.x + (a.base + r.off) : (ones ? (const char*)&g_ones_u8 : zero_page());
+    lo = hi;
+    sh = data ? r.sh : 0;
+  }
+  __device__ void a_ptr(const Ctx& c, const ARow& r, const AK& a, const char*& hi, const char*& lo) const {
+    const bool data = a.ok && r.kind == 1, ones = a.ok && r.kind == 2;
+    hi = data ? c.x + 2ull * (a.base + r.off) : (ones ? (const char*)&g_ones_chunk : zero_page());
+    lo = data ? hi + 2 * g.C : zero_page();
+  }
+  __device__ void b_row(const Ctx&, int n, BRow& b) const { b.ok = n < g.F; b.n = b.ok ? n : 0; }
+  __device__ void b_k(const Ctx&, int k, int kend, BK_& b) const { b.ok = k < kend; b.off = b.ok ? (uint32_t)k * 2 * g.F : 0; }
+  __device__ void b_ptr(const Ctx& c, const BRow& n, const BK_& k, const char*& hi, const char*& lo) const {
+    const bool ok = n.ok && k.ok;
+    hi = ok ? (const char*)(c.dz + k.off + n.n) : zero_page();
+    lo = hi + 2 * g.F;
+  }
+  __device__ void o_row(const Ctx&, int m, ORow& o) const {
+    if constexpr (U8) {
+      const int ky = m >> 5, j = m & 31, run = g.KW * g.C;
+      o.base = (ky < g.KH && j < run) ? (ky * run + j) * g.F : (m == g.KH * 32 ? kkc * g.F : -1);
+    } else {
+      o.base = m * g.F;
+    }
+  }
+  __device__ void o_col(const Ctx&, int, OCol&) const {}
+  __device__ float o_aux(const Ctx&, const ORow&, int, int) const { return 0.f; }
+  __device__ void store(const Ctx& c, const ORow& o, const OCol&, int n, int split, float v, float) const {
+    if (o.base < 0) return;
+    // the ones row must not be scaled: its row index is kkc
+    const float sc = (o.base == kkc * g.F) ? 1.f : scale;
+    c.slab[(size_t)split * (size_t)((kkc + 1) * g.F) + o.base + n] = v * sc;
+  }
+};
+
+// ------------------------------------------------------------------------------ format kernels
+// fp32 [rows][cols] <-> S format
+__global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ in, ushort_t* __restrict__ out, long long rows, int cols) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * cols) return;
+  const long long r = i / cols;
+  const int c = (int)(i - r * cols);
+  ushort_t h, l;
+  split1(in[i], h, l);
+  out[(r * 2) * cols + c] = h;
+  out[(r * 2 + 1) * cols + c] = l;
+}
+__global__ __launch_bounds__(256) void merge_kernel(const ushort_t* __restrict__ in, float* __restrict__ out, long long rows, int cols) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * cols) return;
+  const long long r = i / cols;
+  const int c = (int)(i - r * cols);
+  const float h = __uint_as_float((uint32_t)in[(r * 2) * cols + c] << 16), l = __uint_as_float((uint32_t)in[(r * 2 + 1) * cols + c] << 16);
+  out[i] = h + l;
+}
+
+// HWIO fp32 kernel -> wf (S format [F][2][Kp], forward B operand) and wd (S format [(ky,kx,c)][2][F], dgrad B operand)
+struct PrepArgs {
+  const float* w[MAXG]; ushort_t* wf[MAXG]; ushort_t* wd[MAXG];
+  int KH, KWC, F, Kp, pad32;
+};
+__global__ __launch_bounds__(256) void prep_weights_kernel(const PrepArgs a) {
+  const int gi = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;      // over Kp * F, f fastest
+  if (i >= a.Kp * a.F) return;
+  const int kp = i / a.F, f = i - kp * a.F;
+  int k = kp;
+  bool valid = true;
+  if (a.pad32) {
+    const int ky = kp >> 5, j = kp & 31;
+    valid = j < a.KWC;
+    k = ky * a.KWC + j;
+  }
+  ushort_t h = 0, l = 0;
+  if (valid) split1(a.w[gi][(size_t)k * a.F + f], h, l);
+  a.wf[gi][(size_t)(f * 2) * a.Kp + kp] = h;
+  a.wf[gi][(size_t)(f * 2 + 1) * a.Kp + kp] = l;
+  if (valid && a.wd[gi] != nullptr) {
+    a.wd[gi][(size_t)(k * 2) * a.F + f] = h;
+    a.wd[gi][(size_t)(k * 2 + 1) * a.F + f] = l;
+  }
+}
+
+// ------------------------------------------------------------------------------ host API
+#ifndef CONVS_BK
+#define CONVS_BK 32
+#endif
+typedef TileCfg<128, 128, CONVS_BK, 2, 2> S128x128;
+typedef TileCfg<128, 64, CONVS_BK, 2, 2> S128x64;
+typedef TileCfg<128, 32, CONVS_BK, 4, 1> S128x32;
+
+template <class P>
+static int s_launch_by_n(const P& p, int max_m, int n, int nsplit, int nz, hipStream_t st, const char* name) {
+  if (n <= 32) return sgemm_launch<P, S128x32>(p, max_m, n, nsplit, nz, st, name);
+  if (n <= 64) return sgemm_launch<P, S128x64>(p, max_m, n, nsplit, nz, st, name);
+  return sgemm_launch<P, S128x128>(p, max_m, n, nsplit, nz, st, name);
+}
+
+static bool all_aligned16(const void* const* ps, int n) {
+  for (int i = 0; i < n; ++i)
+    if (ps[i] == nullptr || (((uintptr_t)ps[i]) & 15)) return false;
+  return true;
+}
+
+static int s_kp(int in_u8, int KH, int KW, int C) { return in_u8 ? KH * 32 : KH * KW * C; }
+
+extern "C" long long serl_convs_weight_bytes(int in_u8, int KH, int KW, int C, int F) {
+  return 4ll * s_kp(in_u8, KH, KW, C) * F;
+}
+
+extern "C" int serl_split_f32(const float* in, void* out, long long rows, int cols, void* stream) {
+  SERL_CHECK_ARG(in && out && rows >= 1 && cols >= 1, "split_f32: bad args");
+  hipLaunchKernelGGL(split_kernel, dim3((unsigned)cdivll(rows * cols, 256)), dim3(256), 0, (hipStream_t)stream, in, (ushort_t*)out, rows, cols);
+  SERL_CHECK_LAUNCH("split_f32");
+  return SERL_OK;
+}
+
+extern "C" int serl_merge_split(const void* in, float* out, long long rows, int cols, void* stream) {
+  SERL_CHECK_ARG(in && out && rows >= 1 && cols >= 1, "merge_split: bad args");
+  hipLaunchKernelGGL(merge_kernel, dim3((unsigned)cdivll(rows * cols, 256)), dim3(256), 0, (hipStream_t)stream, (const ushort_t*)in, out, rows, cols);
+  SERL_CHECK_LAUNCH("merge_split");
+  return SERL_OK;
+}
+
+extern "C" int serl_convs_prep_weights(int ngroups, const float* const* w, void* const* wf, void* const* wd, int in_u8,
+                                       int KH, int KW, int C, int F, void* stream) {
+  SERL_CHECK_ARG(ngroups >= 1 && ngroups <= MAXG, "convs_prep_weights: ngroups must be in [1,%d]", MAXG);
+  SERL_CHECK_ARG(KH > 0 && KW > 0 && C > 0 && F > 0 && F % 8 == 0, "convs_prep_weights: F must be a multiple of 8");
+  SERL_CHECK_ARG(in_u8 ? KW * C <= 32 : C % 8 == 0, "convs_prep_weights: need C %% 8 == 0 (or KW*C <= 32 for uint8 input)");
+  PrepArgs a;
+  a.KH = KH; a.KWC = KW * C; a.F = F; a.Kp = s_kp(in_u8, KH, KW, C); a.pad32 = in_u8;
+  for (int i = 0; i < ngroups; ++i) {
+    SERL_CHECK_ARG(w[i] && wf[i], "convs_prep_weights: null pointer");
+    a.w[i] = w[i]; a.wf[i] = (ushort_t*)wf[i]; a.wd[i] = wd ? (ushort_t*)wd[i] : nullptr;
+  }
+  hipLaunchKernelGGL(prep_weights_kernel, dim3(cdiv(a.Kp * F, 256), ngroups), dim3(256), 0, (hipStream_t)stream, a);
+  SERL_CHECK_LAUNCH("convs_prep_weights");
+  return SERL_OK;
+}
+
+extern "C" int serl_convs_fwd(int ngroups, const void* const* x, const void* const* wf, const float* const* bias,
+                              void* const* y, int in_u8, int B, int IH, int IW, int C, int KH, int KW, int stride, int F,
+                              int relu, void* stream) {
+  SERL_CHECK_ARG(ngroups >= 1 && ngroups <= MAXG, "convs_fwd: ngroups must be in [1,%d]", MAXG);
+  ConvGeom g;
+  if (int e = make_geom(g, B, IH, IW, C, KH, KW, stride, F)) return e;
+  SERL_CHECK_ARG(F % 8 == 0 && (in_u8 ? KW * C <= 32 : C % 8 == 0), "convs_fwd: need F %% 8 == 0 and C %% 8 == 0 (uint8 input: KW*C <= 32)");
+  SERL_CHECK_ARG(all_aligned16(wf, ngroups) && all_aligned16(y, ngroups) && (in_u8 || all_aligned16(x, ngroups)),
+                 "convs_fwd: S-format tensors must be 16-byte aligned");
+  const int M = B * g.OH * g.OW;
+  hipStream_t st = (hipStream_t)stream;
+#define FILL(p)                                                                                              \
+  p.g = g; p.relu = relu; p.Kp = s_kp(in_u8, KH, KW, C); p.scale = in_u8 ? 1.0f / 255.0f : 1.0f;             \
+  p.d_c = make_fastdiv(C); p.d_kw = make_fastdiv(KW);                                                        \
+  for (int i = 0; i < ngroups; ++i) { p.x[i] = x[i]; p.wf[i] = (const ushort_t*)wf[i]; p.bias[i] = bias[i]; p.y[i] = (ushort_t*)y[i]; }
+  if (in_u8) { ConvFwdS<true> p; FILL(p) return s_launch_by_n(p, M, F, 1, ngroups, st, "convs_fwd_u8"); }
+  ConvFwdS<false> p; FILL(p) return s_launch_by_n(p, M, F, 1, ngroups, st, "convs_fwd");
+#undef FILL
+}
+
+extern "C" int serl_convs_dgrad(int ngroups, const void* const* dz, const void* const* wd, const void* const* xact,
+                                void* const* dx, int B, int IH, int IW, int C, int KH, int KW, int stride, int F,
+                                void* stream) {
+  SERL_CHECK_ARG(ngroups >= 1 && ngroups <= MAXG, "convs_dgrad: ngroups must be in [1,%d]", MAXG);
+  ConvGeom g;
+  if (int e = make_geom(g, B, IH, IW, C, KH, KW, stride, F)) return e;
+  SERL_CHECK_ARG(stride <= 2, "convs_dgrad: stride must be 1 or 2");
+  SERL_CHECK_ARG(F % 8 == 0 && C % 8 == 0, "convs_dgrad: need C %% 8 == 0 and F %% 8 == 0");
+  SERL_CHECK_ARG(all_aligned16(dz, ngroups) && all_aligned16(wd, ngroups) && all_aligned16(dx, ngroups),
+                 "convs_dgrad: S-format tensors must be 16-byte aligned");
+  ConvDgradS p; p.g = g; p.G = ngroups;
+  p.d_f_ = make_fastdiv(g.F);
+  for (int ci = 0; ci < stride * stride; ++ci) {
+    ConvDgradS::Cls& k = p.cls[ci];
+    k.py = ci / stride; k.px = ci - k.py * stride;
+    k.IHc = (g.IH - k.py + stride - 1) / stride;
+    k.IWc = (g.IW - k.px + stride - 1) / stride;
+    k.TY = (g.KH - k.py + stride - 1) / stride;
+    k.TX = (g.KW - k.px + stride - 1) / stride;
+    if (k.TY <= 0 || k.TX <= 0) { k.TY = 0; k.TX = 0; }
+    k.d_hw = make_fastdiv(k.IHc * k.IWc > 0 ? k.IHc * k.IWc : 1);
+    k.d_w = make_fastdiv(k.IWc > 0 ? k.IWc : 1);
+    k.d_tx = make_fastdiv(k.TX > 0 ? k.TX : 1);
+  }
+  for (int i = 0; i < ngroups; ++i) {
+    p.dz[i] = (const ushort_t*)dz[i]; p.wd[i] = (const ushort_t*)wd[i];
+    p.xact[i] = xact ? (const ushort_t*)xact[i] : nullptr; p.dx[i] = (ushort_t*)dx[i];
+  }
+  const int max_m = g.B * cdiv(g.IH, stride) * cdiv(g.IW, stride);
+  return s_launch_by_n(p, max_m, g.C, 1, ngroups * stride * stride, (hipStream_t)stream, "convs_dgrad");
+}
+
+extern "C" int serl_convs_wgrad(int ngroups, const void* const* x, const void* const* dz, float* const* dw,
+                                float* const* dbias, float* workspace, long long workspace_bytes, int in_u8, int B,
+                                int IH, int IW, int C, int KH, int KW, int stride, int F, void* stream) {
+  SERL_CHECK_ARG(ngroups >= 1 && ngroups <= MAXG, "convs_wgrad: ngroups must be in [1,%d]", MAXG);
+  ConvGeom g;
+  if (int e = make_geom(g, B, IH, IW, C, KH, KW, stride, F)) return e;
+  SERL_CHECK_ARG(F % 8 == 0 && (in_u8 ? KW * C <= 32 : C % 8 == 0), "convs_wgrad: need F %% 8 == 0 and C %% 8 == 0 (uint8 input: KW*C <= 32)");
+  SERL_CHECK_ARG(all_aligned16(dz, ngroups) && (in_u8 || all_aligned16(x, ngroups)), "convs_wgrad: S-format tensors must be 16-byte aligned");
+  int nsplit, klen;
+  wgrad_plan(g, ngroups, nsplit, klen);
+  const int kkc = KH * KW * C;
+  const long long need = (long long)ngroups * nsplit * (kkc + 1) * F * 4ll;
+  SERL_CHECK_ARG(workspace != nullptr && workspace_bytes >= need, "convs_wgrad: workspace too small (%lld < %lld)",
+                 workspace_bytes, need);
+  hipStream_t st = (hipStream_t)stream;
+  int e;
+#define FILLW(p)                                                                                      \
+  p.g = g; p.slab = workspace; p.nsplit = nsplit; p.klen = klen; p.kkc = kkc;                          \
+  p.Mp = in_u8 ? KH * 32 + 1 : kkc + 1; p.scale = in_u8 ? 1.0f / 255.0f : 1.0f;                        \
+  p.d_c = make_fastdiv(C); p.d_kw = make_fastdiv(KW);                                                  \
+  for (int i = 0; i < ngroups; ++i) { p.x[i] = x[i]; p.dz[i] = (const ushort_t*)dz[i]; }
+  if (in_u8) { ConvWgradS<true> p; FILLW(p) e = s_launch_by_n(p, p.Mp, F, nsplit, ngroups, st, "convs_wgrad_u8"); }
+  else { ConvWgradS<false> p; FILLW(p) e = s_launch_by_n(p, p.Mp, F, nsplit, ngroups, st, "convs_wgrad"); }
+#undef FILLW
+  if (e) return e;
+  ReduceArgs ra; ra.slab = workspace; ra.nsplit = nsplit; ra.kkc = kkc; ra.F = F;
+  for (int i = 0; i < ngroups; ++i) { ra.dw[i] = dw[i]; ra.db[i] = dbias[i]; }
+  dim3 grid(cdiv((kkc + 1) * F, 64), ngroups);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, grid, dim3(256), 0, st, ra);
+  SERL_CHECK_LAUNCH("wgrad_reduce");
+  return SERL_OK;
+}

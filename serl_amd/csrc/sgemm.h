@@ -1,0 +1,285 @@
+// Implicit GEMM over operands that are ALREADY split into bf16 hi / lo planes ("S format") in HBM.
+//
+// S format of a [rows][cols] fp32 tensor (cols % 8 == 0): ushort[rows][2][cols] -- for every row the cols
+// bf16 "hi" values (hi = bf16_rn(x)) followed by the cols bf16 "lo" values (lo = bf16_rn(x - hi)); the same
+// 4 bytes per element as fp32.  The conv stack keeps its activations, activation gradients and (re-laid-out)
+// weights in this format at precision "bf16_3x", so the GEMM main loop is pure data movement + MFMA:
+//   global 16-B chunk (8 bf16 of one plane) -> registers -> LDS image -> MFMA fragments,
+//   acc += a_lo*b_hi + a_hi*b_lo + a_hi*b_hi   (v_mfma_f32_32x32x16_bf16, fp32 accumulate)
+// with no per-element conversion, masking or index arithmetic (the in-kernel split of igemm_bf3.h costs
+// ~140 VALU instructions per K=16 step and makes that kernel instruction-issue bound).
+//
+// Operand images in LDS, per plane:
+//   KC (chunk = 8 consecutive k of one row)  : [rows][BK+8] bf16, fragment = one ds_read_b128
+//   RC (chunk = 8 consecutive rows of one k) : [BK][row stride] bf16, fragment = two ds_read_b64_tr_b16
+//       (hardware transpose read: lane i of a 16-lane group gets column i of a 4(k) x 16(rows) block);
+//       row stride = 64 B mod 128 B so that the four k-rows of a block fall in disjoint banks.
+// Out-of-range chunks are read from a zero page (pointer select, no data select).  uint8 operands (the
+// first conv layer's pixels) are loaded as 8 bytes and widened to bf16 after the MFMAs; they have no lo plane.
+#pragma once
+#include "igemm_bf3.h"
+
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));   // native vector: stays in registers (HIP's uint4 struct does not)
+
+__device__ uint4 g_zero_page[512];                       // 8 KB of zeros (never written)
+__device__ uint4 g_ones_chunk = {0x00003F80u, 0u, 0u, 0u};  // bf16 (1, 0, 0, 0, 0, 0, 0, 0)
+
+struct __attribute__((packed, aligned(1))) U8x8 { unsigned long long v; };
+
+// 4 bytes -> 4 bf16 (exact: integers 0..255)
+__device__ __forceinline__ uint2 u8x4_to_bf16(uint32_t v) {
+  const uint32_t f0 = __float_as_uint((float)(v & 0xffu)), f1 = __float_as_uint((float)((v >> 8) & 0xffu));
+  const uint32_t f2 = __float_as_uint((float)((v >> 16) & 0xffu)), f3 = __float_as_uint((float)(v >> 24));
+  return make_uint2(__builtin_amdgcn_perm(f1, f0, 0x07060302u), __builtin_amdgcn_perm(f3, f2, 0x07060302u));
+}
+
+constexpr int s_rc_stride(int rows) { return ((2 * rows - 64 + 127) / 128) * 128 + 64; }   // bytes
+
+// Problem interface (all __device__):
+//   static constexpr bool A_KC, B_KC (image kind), A_LO, B_LO (operand has a lo plane), A_U8 (A chunks are bytes);
+//   Ctx, ARow, AK, BRow, BK_, ORow, OCol;  init / M / N / K / ksplit_len as in igemm.h;
+//   KC operand: a_row(ctx, m, ARow&) per row, a_k(ctx, k, kend, AK&) per chunk (k % 8 == 0);
+//   RC operand: a_row(ctx, m, ARow&) per 8-row chunk (m % 8 == 0), a_k(ctx, k, kend, AK&) per k;
+//   a_ptr(ctx, ARow, AK, const char*& hi, const char*& lo [, int& shift for A_U8]) -- always-valid addresses
+//   (zero page when out of range); same for b_*;  epilogue members as in igemm.h.
+template <class P, class T>
+__global__ __launch_bounds__(256, 2) void sgemm_kernel(const P p) {
+  constexpr int BM = T::BM, BN = T::BN, BK = T::BK, TM = T::TM, TN = T::TN;
+  static_assert(BK == 16 || BK == 32, "K slab");
+  constexpr bool AKC = P::A_KC, BKC = P::B_KC, ALO = P::A_LO, BLO = P::B_LO, AU8 = P::A_U8;
+  constexpr int KC_STRIDE = (BK + 8) * 2;                               // bytes per row of a KC image
+  constexpr int A_STRIDE = AKC ? KC_STRIDE : s_rc_stride(BM);
+  constexpr int B_STRIDE = BKC ? KC_STRIDE : s_rc_stride(BN);
+  constexpr int A_PLANE = AKC ? BM * KC_STRIDE : BK * A_STRIDE;         // bytes
+  constexpr int B_PLANE = BKC ? BN * KC_STRIDE : BK * B_STRIDE;
+  constexpr int A_BUF = (ALO ? 2 : 1) * A_PLANE, B_BUF = (BLO ? 2 : 1) * B_PLANE;
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_smem[];
+  unsigned char* const As = s_smem;                     // [buf][plane][...]
+  unsigned char* const Bs = s_smem + 2 * A_BUF;
+
+  typename P::Ctx ctx;
+  if (!p.init(ctx, blockIdx.z)) return;
+  const int M = p.M(ctx), N = p.N(ctx), K = p.K(ctx);
+  const int tiles_n = (N + BN - 1) / BN;
+  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  if (m0 >= M) return;
+  const int split = blockIdx.y;
+  const int kbeg = split * p.ksplit_len();
+  const int kend = min(K, kbeg + p.ksplit_len());
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int wm = wid / T::WGN, wn = wid - wm * T::WGN;
+
+  // ---- chunk slots of this thread
+  constexpr int A_DIV = AKC ? BK / 8 : BM / 8;          // chunks along the fast axis of the thread map
+  constexpr int A_STEP = 256 / A_DIV;
+  constexpr int A_EXT = AKC ? BM : BK;
+  constexpr int NA = (A_EXT + A_STEP - 1) / A_STEP;
+  constexpr int B_DIV = BKC ? BK / 8 : BN / 8;
+  constexpr int B_STEP = 256 / B_DIV;
+  constexpr int B_EXT = BKC ? BN : BK;
+  constexpr int NB = (B_EXT + B_STEP - 1) / B_STEP;
+  const int a_f = (tid % A_DIV) * 8, a_s = tid / A_DIV;   // fast-axis element offset, slow-axis index
+  const int b_f = (tid % B_DIV) * 8, b_s = tid / B_DIV;
+  typename P::ARow arow[AKC ? NA : 1];
+  typename P::BRow brow[BKC ? NB : 1];
+  if constexpr (AKC) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) p.a_row(ctx, m0 + a_s + i * A_STEP, arow[i]);
+  } else {
+    p.a_row(ctx, m0 + a_f, arow[0]);
+  }
+  if constexpr (BKC) {
+#pragma unroll
+    for (int i = 0; i < NB; ++i) p.b_row(ctx, n0 + b_s + i * B_STEP, brow[i]);
+  } else {
+    p.b_row(ctx, n0 + b_f, brow[0]);
+  }
+  const bool a_on = (NA * A_STEP == A_EXT) || (a_s < A_EXT);
+  const bool b_on = (NB * B_STEP == B_EXT) || (b_s < B_EXT);
+
+  // two register sets: the loads of K-step t+2 are issued while step t is multiplied and step t+1 (loaded one
+  // iteration earlier) is written to LDS -- one step of lookahead left every K-step waiting a full HBM round trip.
+  u32x4_t ahi[2][NA], alo[2][ALO ? NA : 1], bhi[2][NB], blo[2][BLO ? NB : 1];
+  unsigned long long a8[2][AU8 ? NA : 1];
+  int a8sh[2][AU8 ? NA : 1];
+  auto gload = [&](auto set_tag, int k0) {
+    constexpr int S_ = decltype(set_tag)::value;
+#ifdef SG_NO_LOAD   // experiment: only the first two K-steps are loaded
+    if (k0 >= kbeg + 2 * BK) return;
+#endif
+    if (a_on) {
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        typename P::AK ak;
+        const char *ph, *pl;
+        if constexpr (AKC) {
+          p.a_k(ctx, k0 + a_f, kend, ak);
+        } else {
+          p.a_k(ctx, k0 + a_s + i * A_STEP, kend, ak);
+        }
+        if constexpr (AU8) {
+          p.a_ptr(ctx, arow[AKC ? i : 0], ak, ph, pl, a8sh[S_][i]);
+          a8[S_][i] = reinterpret_cast<const U8x8*>(ph)->v;
+        } else {
+          p.a_ptr(ctx, arow[AKC ? i : 0], ak, ph, pl);
+          ahi[S_][i] = *reinterpret_cast<const u32x4_t*>(ph);
+          if constexpr (ALO) alo[S_][i] = *reinterpret_cast<const u32x4_t*>(pl);
+        }
+      }
+    }
+    if (b_on) {
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        typename P::BK_ bk;
+        const char *ph, *pl;
+        if constexpr (BKC) {
+          p.b_k(ctx, k0 + b_f, kend, bk);
+        } else {
+          p.b_k(ctx, k0 + b_s + i * B_STEP, kend, bk);
+        }
+        p.b_ptr(ctx, brow[BKC ? i : 0], bk, ph, pl);
+        bhi[S_][i] = *reinterpret_cast<const u32x4_t*>(ph);
+        if constexpr (BLO) blo[S_][i] = *reinterpret_cast<const u32x4_t*>(pl);
+      }
+    }
+  };
+  auto lstore = [&](auto set_tag, int buf) {
+    constexpr int S_ = decltype(set_tag)::value;
+    unsigned char* As_ = As + buf * A_BUF;
+    unsigned char* Bs_ = Bs + buf * B_BUF;
+    if (a_on) {
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        const int off = AKC ? (a_s + i * A_STEP) * KC_STRIDE + a_f * 2 : (a_s + i * A_STEP) * A_STRIDE + a_f * 2;
+        if constexpr (AU8) {
+          const unsigned long long v = a8[S_][i] >> a8sh[S_][i];
+          const uint2 lo2 = u8x4_to_bf16((uint32_t)v), hi2 = u8x4_to_bf16((uint32_t)(v >> 32));
+          const u32x4_t w = {lo2.x, lo2.y, hi2.x, hi2.y};
+          *reinterpret_cast<u32x4_t*>(As_ + off) = w;
+        } else {
+          *reinterpret_cast<u32x4_t*>(As_ + off) = ahi[S_][i];
+          if constexpr (ALO) *reinterpret_cast<u32x4_t*>(As_ + A_PLANE + off) = alo[S_][i];
+        }
+      }
+    }
+    if (b_on) {
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int off = BKC ? (b_s + i * B_STEP) * KC_STRIDE + b_f * 2 : (b_s + i * B_STEP) * B_STRIDE + b_f * 2;
+        *reinterpret_cast<u32x4_t*>(Bs_ + off) = bhi[S_][i];
+        if constexpr (BLO) *reinterpret_cast<u32x4_t*>(Bs_ + B_PLANE + off) = blo[S_][i];
+      }
+    }
+  };
+  // MFMA fragment (32 rows from row0, k-step s) of one plane
+  const int tr_q = (lane & 15) >> 2, tr_p = lane & 3, tr_cb = (lane & 16);
+  auto frag = [&](const unsigned char* img, auto kc_tag, int stride, int row0, int s) -> bf16x8_t {
+    if constexpr (decltype(kc_tag)::value) {
+      return __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(img + (row0 + r) * KC_STRIDE + (s * 2 + h) * 16));
+    } else {
+      typedef __attribute__((address_space(3))) s16x4_t* lds_p;
+      const unsigned char* a0 = img + (s * 16 + 8 * h + tr_q) * stride + (row0 + tr_cb + 4 * tr_p) * 2;
+      const s16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a0));
+      const s16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a0 + 4 * stride));
+      typedef short s16x8_t __attribute__((ext_vector_type(8)));
+      const s16x8_t v = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+      return __builtin_bit_cast(bf16x8_t, v);
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+  auto mma = [&](int cur) {
+#ifdef SG_NO_MMA
+    return;
+#endif
+    const unsigned char* Ah = As + cur * A_BUF;
+    const unsigned char* Bh = Bs + cur * B_BUF;
+#pragma unroll
+    for (int s = 0; s < BK / 16; ++s) {
+      bf16x8_t ah[TM], al[ALO ? TM : 1], bh[TN], bl[BLO ? TN : 1];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        ah[i] = frag(Ah, std::integral_constant<bool, AKC>{}, A_STRIDE, wm * (TM * 32) + i * 32, s);
+        if constexpr (ALO) al[i] = frag(Ah + A_PLANE, std::integral_constant<bool, AKC>{}, A_STRIDE, wm * (TM * 32) + i * 32, s);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        bh[j] = frag(Bh, std::integral_constant<bool, BKC>{}, B_STRIDE, wn * (TN * 32) + j * 32, s);
+        if constexpr (BLO) bl[j] = frag(Bh + B_PLANE, std::integral_constant<bool, BKC>{}, B_STRIDE, wn * (TN * 32) + j * 32, s);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          if constexpr (ALO) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          if constexpr (BLO) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+  };
+  constexpr std::integral_constant<int, 0> S0{};
+  constexpr std::integral_constant<int, 1> S1{};
+  // Loads and LDS writes are unconditional (a step past kend reads the zero page into a buffer nobody multiplies):
+  // with straight-line code hipcc counts vmcnt exactly, so writing set t+1 does not drain the loads of t+2.
+  gload(S0, kbeg);
+  gload(S1, kbeg + BK);
+  lstore(S0, 0);
+  __syncthreads();
+  int cur = 0;
+  for (int k0 = kbeg; k0 < kend; k0 += 2 * BK) {
+    // even step: multiply step t; set 1 holds t+1; set 0 is free -> t+2
+    gload(S0, k0 + 2 * BK);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(cur);
+    __builtin_amdgcn_sched_barrier(0);
+    lstore(S1, cur ^ 1);
+    __syncthreads();
+    if (k0 + BK >= kend) break;
+    // odd step: multiply t+1; set 0 holds t+2; set 1 is free -> t+3
+    gload(S1, k0 + 3 * BK);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(cur ^ 1);
+    __builtin_amdgcn_sched_barrier(0);
+    lstore(S0, cur);
+    __syncthreads();
+  }
+  igemm_epilogue<P, T>(p, ctx, acc, M, N, m0, n0, wm, wn, r, h, split);
+}
+
+template <class P, class T>
+constexpr int sgemm_lds_bytes() {
+  constexpr int KC_STRIDE = (T::BK + 8) * 2;
+  constexpr int A_PLANE = P::A_KC ? T::BM * KC_STRIDE : T::BK * s_rc_stride(T::BM);
+  constexpr int B_PLANE = P::B_KC ? T::BN * KC_STRIDE : T::BK * s_rc_stride(T::BN);
+  return 2 * ((P::A_LO ? 2 : 1) * A_PLANE + (P::B_LO ? 2 : 1) * B_PLANE);
+}
+
+template <class P, class T>
+static inline int sgemm_launch(const P& p, int max_m, int max_n, int nsplit, int nz, hipStream_t st, const char* name) {
+  const int tiles = cdiv(max_m, T::BM) * cdiv(max_n, T::BN);
+  if (tiles <= 0 || nsplit <= 0 || nz <= 0) return SERL_OK;
+  constexpr int lds = sgemm_lds_bytes<P, T>();
+  static_assert(lds <= 160 * 1024, "tile does not fit the 160 KB LDS");
+  static bool opted[64] = {};
+  int dev = 0;
+  SERL_CHECK_HIP(hipGetDevice(&dev), name);
+  if (lds > 48 * 1024 && dev >= 0 && dev < 64 && !opted[dev]) {
+    SERL_CHECK_HIP(hipFuncSetAttribute((const void*)sgemm_kernel<P, T>, hipFuncAttributeMaxDynamicSharedMemorySize, lds), name);
+    opted[dev] = true;
+  }
+  dim3 grid(tiles, nsplit, nz);
+  hipLaunchKernelGGL((sgemm_kernel<P, T>), grid, dim3(256), lds, st, p);
+  SERL_CHECK_LAUNCH(name);
+  return SERL_OK;
+}

@@ -53,11 +53,25 @@ def _ksplit(K):
 
 
 # =============================================================================== encoder
+def split_conv_stack(cfg: NetConfig) -> bool:
+    """True when the conv stack runs on S-format tensors (include/serl_hip.h): precision "bf16_3x" and every
+    layer's channel counts fit the format (first layer: uint8 pixels with KW*C <= 32; then C, F multiples of 8).
+    The activation buffers have the same byte size either way (4 bytes per element)."""
+    from .. import get_matmul_precision
+    if get_matmul_precision() != "bf16_3x":
+        return False
+    for li, L in enumerate(cfg.conv_layers()):
+        if L.F % 8 or (L.K * L.C > 32 if li == 0 else L.C % 8) or L.S > 2:
+            return False
+    return True
+
+
 def encoder_fwd(cfg: NetConfig, passes, B, ws: Workspace, st):
     """passes: list of (tag, ParamStore, [u8 image ptr per camera in cfg.cams order]).
     All passes x cameras run as groups of one launch per conv layer. Writes ws['enc_<tag>'] (B, enc_dim)."""
     layers = cfg.conv_layers()
     nl, ncam = len(layers), len(cfg.cams)
+    split = split_conv_stack(cfg)
     groups = [(tag, store, ci, imgs[ci]) for tag, store, imgs in passes for ci in range(ncam)]
     for g0 in range(0, len(groups), 8):
         chunk = groups[g0:g0 + 8]
@@ -66,14 +80,22 @@ def encoder_fwd(cfg: NetConfig, passes, B, ws: Workspace, st):
             wsp = [g[1].ptr("image_encoder", f"Conv_{g[2] * nl + li}", "kernel") for g in chunk]
             bsp = [g[1].ptr("image_encoder", f"Conv_{g[2] * nl + li}", "bias") for g in chunk]
             ys = [ws.ptr(f"act{li}_{g[0]}_{g[2]}", (B, L.OH, L.OW, L.F)) for g in chunk]
-            ops.conv2d_fwd(xs, wsp, bsp, ys, li == 0, B, L.IH, L.IW, L.C, L.K, L.K, L.S, L.F, True, st)
+            if split:
+                nwf = ops.convs_weight_bytes(li == 0, L.K, L.K, L.C, L.F) // 4
+                wfs = [ws.ptr(f"wf{li}_{g[0]}_{g[2]}", (nwf,)) for g in chunk]
+                wds = [ws.ptr(f"wd{li}_{g[0]}_{g[2]}", (L.K * L.K * L.C * L.F,)) for g in chunk] if li > 0 else None
+                ops.convs_prep_weights(wsp, wfs, wds, li == 0, L.K, L.K, L.C, L.F, st)
+                ops.convs_fwd(xs, wfs, bsp, ys, li == 0, B, L.IH, L.IW, L.C, L.K, L.K, L.S, L.F, True, st)
+            else:
+                ops.conv2d_fwd(xs, wsp, bsp, ys, li == 0, B, L.IH, L.IW, L.C, L.K, L.K, L.S, L.F, True, st)
             xs = ys
     last = layers[-1]
     for tag, store, ci, _ in groups:
         enc = ws.ptr(f"enc_{tag}", (B, cfg.enc_dim))
         feat = ws.ptr(f"act{nl - 1}_{tag}_{ci}", (B, last.OH, last.OW, last.F))
         ops.sle_fwd(feat, store.ptr("image_encoder", f"SpatialLearnedEmbeddings_{ci}", "kernel"),
-                    enc + 4 * ci * last.F * SLE_FEATURES, cfg.enc_dim, B, last.OH * last.OW, last.F, SLE_FEATURES, st)
+                    enc + 4 * ci * last.F * SLE_FEATURES, cfg.enc_dim, B, last.OH * last.OW, last.F, SLE_FEATURES, st,
+                    feat_split=split)
 
 
 def encoder_bwd(cfg: NetConfig, tag, store, grads, imgs, B, ws: Workspace, st):
@@ -81,6 +103,7 @@ def encoder_bwd(cfg: NetConfig, tag, store, grads, imgs, B, ws: Workspace, st):
     layers = cfg.conv_layers()
     nl, ncam = len(layers), len(cfg.cams)
     last = layers[-1]
+    split = split_conv_stack(cfg)      # same decision as the forward that filled act* / wd* for this tag
     denc = ws.ptr(f"denc_{tag}", (B, cfg.enc_dim))
     for ci in range(ncam):
         feat = ws.ptr(f"act{nl - 1}_{tag}_{ci}", (B, last.OH, last.OW, last.F))
@@ -88,7 +111,7 @@ def encoder_bwd(cfg: NetConfig, tag, store, grads, imgs, B, ws: Workspace, st):
         ops.sle_bwd(denc + 4 * ci * last.F * SLE_FEATURES, cfg.enc_dim,
                     store.ptr("image_encoder", f"SpatialLearnedEmbeddings_{ci}", "kernel"), feat, dfeat,
                     grads.ptr("image_encoder", f"SpatialLearnedEmbeddings_{ci}", "kernel"),
-                    B, last.OH * last.OW, last.F, SLE_FEATURES, st)
+                    B, last.OH * last.OW, last.F, SLE_FEATURES, st, feat_split=split)
     slab_bytes = max(ops.conv2d_wgrad_workspace_bytes(ncam, B, L.IH, L.IW, L.C, L.K, L.K, L.S, L.F) for L in layers)
     slab = ws.ptr("wgrad_slab", (slab_bytes // 4,))
     for li in range(nl - 1, -1, -1):
@@ -99,15 +122,20 @@ def encoder_bwd(cfg: NetConfig, tag, store, grads, imgs, B, ws: Workspace, st):
         else:
             P = layers[li - 1]
             xs = [ws.ptr(f"act{li - 1}_{tag}_{ci}", (B, P.OH, P.OW, P.F)) for ci in range(ncam)]
-        ops.conv2d_wgrad(xs, dz,
-                         [grads.ptr("image_encoder", f"Conv_{ci * nl + li}", "kernel") for ci in range(ncam)],
-                         [grads.ptr("image_encoder", f"Conv_{ci * nl + li}", "bias") for ci in range(ncam)],
-                         slab, slab_bytes, li == 0, B, L.IH, L.IW, L.C, L.K, L.K, L.S, L.F, st)
+        (ops.convs_wgrad if split else ops.conv2d_wgrad)(
+            xs, dz,
+            [grads.ptr("image_encoder", f"Conv_{ci * nl + li}", "kernel") for ci in range(ncam)],
+            [grads.ptr("image_encoder", f"Conv_{ci * nl + li}", "bias") for ci in range(ncam)],
+            slab, slab_bytes, li == 0, B, L.IH, L.IW, L.C, L.K, L.K, L.S, L.F, st)
         if li > 0:
             P = layers[li - 1]
             dx = [ws.ptr(f"dact{li - 1}_{ci}", (B, P.OH, P.OW, P.F)) for ci in range(ncam)]
-            ops.conv2d_dgrad(dz, [store.ptr("image_encoder", f"Conv_{ci * nl + li}", "kernel") for ci in range(ncam)],
-                             xs, dx, B, L.IH, L.IW, L.C, L.K, L.K, L.S, L.F, st)
+            if split:
+                wds = [ws.ptr(f"wd{li}_{tag}_{ci}", (L.K * L.K * L.C * L.F,)) for ci in range(ncam)]
+                ops.convs_dgrad(dz, wds, xs, dx, B, L.IH, L.IW, L.C, L.K, L.K, L.S, L.F, st)
+            else:
+                ops.conv2d_dgrad(dz, [store.ptr("image_encoder", f"Conv_{ci * nl + li}", "kernel") for ci in range(ncam)],
+                                 xs, dx, B, L.IH, L.IW, L.C, L.K, L.K, L.S, L.F, st)
 
 
 # =============================================================================== trunk

@@ -79,6 +79,69 @@ def conv2d_wgrad(xs, dzs, dws, dbs, workspace, workspace_bytes, in_u8, B, IH, IW
          stride, F, stream)
 
 
+# ---- S-format conv stack (precision "bf16_3x"; include/serl_hip.h)
+def convs_weight_bytes(in_u8, KH, KW, C, F) -> int:
+    return int(_lib.load().serl_convs_weight_bytes(int(in_u8), KH, KW, C, F))
+
+
+def split_f32(src, dst, rows, cols, stream):
+    call("serl_split_f32", src, dst, rows, cols, stream)
+
+
+def merge_split(src, dst, rows, cols, stream):
+    call("serl_merge_split", src, dst, rows, cols, stream)
+
+
+def convs_prep_weights(ws, wfs, wds, in_u8, KH, KW, C, F, stream):
+    n = len(ws)
+    pw, kw = ptr_table(ws); pf, kf = ptr_table(wfs)
+    if wds is None:
+        pd = None
+    else:
+        pd, kd = ptr_table(wds)
+    call("serl_convs_prep_weights", n, pw, pf, pd, int(in_u8), KH, KW, C, F, stream)
+
+
+def convs_fwd(xs, wfs, bs, ys, in_u8, B, IH, IW, C, KH, KW, stride, F, relu, stream):
+    n = len(xs)
+    px, kx = ptr_table(xs); pw, kw = ptr_table(wfs); pb, kb = ptr_table(bs); py, ky = ptr_table(ys)
+    ev = None
+    if TIMER is not None:
+        OH, OW = (IH - KH) // stride + 1, (IW - KW) // stride + 1
+        ev = TIMER.bracket(("convs_fwd", bool(in_u8), n, B, IH, C, F), 2.0 * n * B * OH * OW * F * KH * KW * C)
+        ev[0].record()
+    call("serl_convs_fwd", n, px, pw, pb, py, int(in_u8), B, IH, IW, C, KH, KW, stride, F, int(relu), stream)
+    if ev is not None:
+        ev[1].record()
+
+
+def convs_dgrad(dzs, wds, xacts, dxs, B, IH, IW, C, KH, KW, stride, F, stream):
+    n = len(dzs)
+    pz, kz = ptr_table(dzs); pw, kw = ptr_table(wds); pa, ka = ptr_table(xacts); pd, kd = ptr_table(dxs)
+    ev = None
+    if TIMER is not None:
+        OH, OW = (IH - KH) // stride + 1, (IW - KW) // stride + 1
+        ev = TIMER.bracket(("convs_dgrad", False, n, B, IH, C, F), 2.0 * n * B * OH * OW * F * KH * KW * C)
+        ev[0].record()
+    call("serl_convs_dgrad", n, pz, pw, pa, pd, B, IH, IW, C, KH, KW, stride, F, stream)
+    if ev is not None:
+        ev[1].record()
+
+
+def convs_wgrad(xs, dzs, dws, dbs, workspace, workspace_bytes, in_u8, B, IH, IW, C, KH, KW, stride, F, stream):
+    n = len(xs)
+    px, kx = ptr_table(xs); pz, kz = ptr_table(dzs); pw, kw = ptr_table(dws); pb, kb = ptr_table(dbs)
+    ev = None
+    if TIMER is not None:
+        OH, OW = (IH - KH) // stride + 1, (IW - KW) // stride + 1
+        ev = TIMER.bracket(("convs_wgrad", bool(in_u8), n, B, IH, C, F), 2.0 * n * B * OH * OW * F * KH * KW * C)
+        ev[0].record()
+    call("serl_convs_wgrad", n, px, pz, pw, pb, workspace, workspace_bytes, int(in_u8), B, IH, IW, C, KH, KW,
+         stride, F, stream)
+    if ev is not None:
+        ev[1].record()
+
+
 def gemm(a, b, c, bias, nbatch, M, N, K, *, a_zs=0, a_ms, a_ks, b_zs=0, b_ks, b_ns, c_zs=0, c_ms,
          bias_zs=0, seglen=None, a_ss=0, b_ss=0, nsplit=1, c_split_stride=0, relu=False, accumulate=False,
          a_kcontig=True, b_ncontig=True, stream=0):
@@ -147,12 +210,12 @@ def temperature_update(state, sum_logp, inv_batch, target_entropy, lr, b1, b2, e
          float(b2), float(eps), float(bc1), float(bc2), info_out, stream)
 
 
-def sle_fwd(feat, ker, out, ldo, B, HW, C, F, stream):
-    call("serl_sle_fwd", feat, ker, out, ldo, B, HW, C, F, stream)
+def sle_fwd(feat, ker, out, ldo, B, HW, C, F, stream, feat_split=False):
+    call("serl_sle_fwd", feat, ker, out, ldo, B, HW, C, F, int(feat_split), stream)
 
 
-def sle_bwd(dout, ldo, ker, feat, dfeat, dker, B, HW, C, F, stream):
-    call("serl_sle_bwd", dout, ldo, ker, feat, dfeat, dker, B, HW, C, F, stream)
+def sle_bwd(dout, ldo, ker, feat, dfeat, dker, B, HW, C, F, stream, feat_split=False):
+    call("serl_sle_bwd", dout, ldo, ker, feat, dfeat, dker, B, HW, C, F, int(feat_split), stream)
 
 
 def gather_crop_frames(frames, cap, indx, T, t0, off, out, n, H, W, S, pad, stream):

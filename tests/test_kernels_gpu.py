@@ -112,6 +112,106 @@ def test_conv_fwd_dgrad_wgrad(dev, case, prec):
             close(dxs[g].cpu().numpy(), ref_dx, rtol=tol, what=f"conv dgrad g{g}")
 
 
+# ---------------------------------------------------------------------------------- sgemm: S-format conv stack
+def _to_s(ops, t, rows, cols, st):
+    """fp32 device tensor -> (S-format device buffer, the fp32 values it represents)."""
+    buf = torch.empty(rows * cols * 2, dtype=torch.int16, device=t.device)
+    ops.split_f32(t.data_ptr(), buf.data_ptr(), rows, cols, st)
+    back = torch.empty(rows * cols, dtype=torch.float32, device=t.device)
+    ops.merge_split(buf.data_ptr(), back.data_ptr(), rows, cols, st)
+    torch.cuda.synchronize()
+    return buf, back.cpu().numpy()
+
+
+def _from_s(ops, buf, rows, cols, st):
+    out = torch.empty(rows * cols, dtype=torch.float32, device=buf.device)
+    ops.merge_split(buf.data_ptr(), out.data_ptr(), rows, cols, st)
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+def test_split_merge_roundtrip(dev):
+    ops = _ops()
+    st = ops.current_stream()
+    x = np.random.default_rng(0).standard_normal((37, 24)).astype(np.float32) * 3
+    _, back = _to_s(ops, dv(x, dev), 37, 24, st)
+    assert np.abs(back.reshape(37, 24) - x).max() <= 2.0 ** -16 * np.abs(x).max()     # 16 mantissa bits kept
+
+
+@pytest.mark.parametrize("case", [c for c in CONV_CASES if c[6] % 8 == 0 and (c[7] or c[3] % 8 == 0)])
+def test_convs_fwd_dgrad_wgrad(dev, case):
+    """Same checks as test_conv_fwd_dgrad_wgrad on the S-format entry points; the float64 reference is fed the
+    values the S-format inputs actually hold. Tolerance 1e-4 of the output scale (bf16_3x products + the 2^-17
+    rounding of the S-format outputs)."""
+    ops = _ops()
+    tol = 1e-4
+    B, IH, IW, Cin, K, S, F, u8 = case
+    rng = np.random.default_rng(1)
+    G = 2
+    st = ops.current_stream()
+    OH, OW = (IH - K) // S + 1, (IW - K) // S + 1
+    xs, wfs, wds, bs, ys, refs, keep = [], [], [], [], [], [], []
+    wb = ops.convs_weight_bytes(u8, K, K, Cin, F)
+    for g in range(G):
+        w = (rng.standard_normal((K, K, Cin, F)) * 0.1).astype(np.float32)
+        b = (rng.standard_normal(F) * 0.1).astype(np.float32)
+        if u8:
+            x = rng.integers(0, 256, size=(B, IH, IW, Cin), dtype=np.uint8)
+            xf = (x.astype(np.float32) / np.float32(255.0))
+            xs.append(dv(x, dev))
+        else:
+            x = np.maximum(rng.standard_normal((B, IH, IW, Cin)).astype(np.float32), 0)
+            buf, xf = _to_s(ops, dv(x, dev), B * IH * IW, Cin, st)
+            xf = xf.reshape(B, IH, IW, Cin)
+            xs.append(buf)
+        W = dv(w, dev)
+        wf = torch.full((wb // 2,), -1, dtype=torch.int16, device=dev)
+        wd = torch.full((K * K * Cin * F * 2,), -1, dtype=torch.int16, device=dev)
+        keep.append(W)
+        wfs.append(wf); wds.append(wd); bs.append(dv(b, dev))
+        ys.append(torch.full((B * OH * OW * F * 2,), -1, dtype=torch.int16, device=dev))
+        refs.append((xf, w, b))
+    ops.convs_prep_weights([t.data_ptr() for t in keep], [t.data_ptr() for t in wfs], [t.data_ptr() for t in wds],
+                           u8, K, K, Cin, F, st)
+    ops.convs_fwd([t.data_ptr() for t in xs], [t.data_ptr() for t in wfs], [t.data_ptr() for t in bs],
+                  [t.data_ptr() for t in ys], u8, B, IH, IW, Cin, K, K, S, F, True, st)
+    torch.cuda.synchronize()
+    dzs, dzf, dxs, dws, dbs = [], [], [], [], []
+    for g in range(G):
+        xf, w, b = refs[g]
+        yref = torch.relu(_conv_ref(xf, w, b, S))
+        got = _from_s(ops, ys[g], B * OH * OW, F, st).reshape(B, OH, OW, F)
+        close(got, yref.numpy(), rtol=tol, what=f"convs fwd g{g}")
+        dz = rng.standard_normal((B, OH, OW, F)).astype(np.float32)
+        dz *= (yref.numpy() > 0)
+        buf, dzv = _to_s(ops, dv(dz, dev), B * OH * OW, F, st)
+        dzs.append(buf); dzf.append(dzv.reshape(B, OH, OW, F))
+        dxs.append(torch.full((B * IH * IW * Cin * 2,), -1, dtype=torch.int16, device=dev))
+        dws.append(torch.full((K, K, Cin, F), float("nan"), device=dev))
+        dbs.append(torch.full((F,), float("nan"), device=dev))
+    wsb = ops.conv2d_wgrad_workspace_bytes(G, B, IH, IW, Cin, K, K, S, F)
+    wsp = torch.empty(wsb // 4, device=dev)
+    ops.convs_wgrad([t.data_ptr() for t in xs], [t.data_ptr() for t in dzs], [t.data_ptr() for t in dws],
+                    [t.data_ptr() for t in dbs], wsp.data_ptr(), wsb, u8, B, IH, IW, Cin, K, K, S, F, st)
+    if not u8:
+        ops.convs_dgrad([t.data_ptr() for t in dzs], [t.data_ptr() for t in wds], [t.data_ptr() for t in xs],
+                        [t.data_ptr() for t in dxs], B, IH, IW, Cin, K, K, S, F, st)
+    torch.cuda.synchronize()
+    for g in range(G):
+        xf, w, b = refs[g]
+        xt = torch.tensor(xf, dtype=torch.float64, requires_grad=True)
+        wt = torch.tensor(w, dtype=torch.float64, requires_grad=True)
+        bt = torch.tensor(b, dtype=torch.float64, requires_grad=True)
+        y = torch.nn.functional.conv2d(xt.permute(0, 3, 1, 2), wt.permute(3, 2, 0, 1), bt, stride=S).permute(0, 2, 3, 1)
+        (y * torch.tensor(dzf[g], dtype=torch.float64)).sum().backward()
+        close(dws[g].cpu().numpy(), wt.grad.numpy(), rtol=tol, what=f"convs wgrad g{g}")
+        close(dbs[g].cpu().numpy(), bt.grad.numpy(), rtol=tol, what=f"convs bias grad g{g}")
+        if not u8:
+            ref_dx = xt.grad.numpy() * (xf > 0)
+            got = _from_s(ops, dxs[g], B * IH * IW, Cin, st).reshape(B, IH, IW, Cin)
+            close(got, ref_dx, rtol=tol, what=f"convs dgrad g{g}")
+
+
 # ---------------------------------------------------------------------------------- igemm: dense
 @pytest.mark.parametrize("dims", [(3, 70, 83, 45), (2, 64, 96, 128)])   # ragged (scalar loads) / aligned (float4 loads)
 def test_gemm_variants(dev, prec, dims):
@@ -246,15 +346,27 @@ def test_rowdot_and_rank1_bwd(dev):
 # ---------------------------------------------------------------------------------- SLE
 @pytest.mark.parametrize("B,HW,C", [(5, 49, 256), (3, 30, 32), (2, 7, 70)])
 def test_sle(dev, B, HW, C):
+    _sle_case(dev, B, HW, C, False)
+
+
+@pytest.mark.parametrize("B,HW,C", [(5, 49, 256), (3, 30, 32)])
+def test_sle_split_features(dev, B, HW, C):
+    _sle_case(dev, B, HW, C, True)
+
+
+def _sle_case(dev, B, HW, C, split):
     ops = _ops()
     rng = np.random.default_rng(5)
     st = ops.current_stream()
     feat = np.maximum(rng.standard_normal((B, HW, C)), 0).astype(np.float32)
     ker = rng.standard_normal((HW, C, 8)).astype(np.float32)
     Fe, Ke = dv(feat, dev), dv(ker, dev)
+    if split:       # S-format features: the reference sees the values they hold; dfeat comes back in S format
+        Fe, featv = _to_s(ops, Fe, B * HW, C, st)
+        feat = featv.reshape(B, HW, C)
     ldo = 2 * C * 8
     out = torch.zeros((B, ldo), device=dev)
-    ops.sle_fwd(Fe.data_ptr(), Ke.data_ptr(), out.data_ptr() + C * 8 * 4, ldo, B, HW, C, 8, st)
+    ops.sle_fwd(Fe.data_ptr(), Ke.data_ptr(), out.data_ptr() + C * 8 * 4, ldo, B, HW, C, 8, st, feat_split=split)
     torch.cuda.synchronize()
     ref = np.einsum("bhc,hcf->bcf", feat.astype(np.float64), ker.astype(np.float64)).reshape(B, -1)
     close(out.cpu().numpy()[:, C * 8:], ref, what="sle fwd")
@@ -263,10 +375,11 @@ def test_sle(dev, B, HW, C):
     DO = dv(dout, dev)
     dfeat = torch.zeros((B, HW, C), device=dev); dker = torch.zeros((HW, C, 8), device=dev)
     ops.sle_bwd(DO.data_ptr() + C * 8 * 4, ldo, Ke.data_ptr(), Fe.data_ptr(), dfeat.data_ptr(), dker.data_ptr(), B, HW,
-                C, 8, st)
+                C, 8, st, feat_split=split)
     torch.cuda.synchronize()
     d = dout[:, C * 8:].reshape(B, C, 8).astype(np.float64)
-    close(dfeat.cpu().numpy(), np.einsum("bcf,hcf->bhc", d, ker.astype(np.float64)) * (feat > 0), what="sle dfeat")
+    got = _from_s(ops, dfeat, B * HW, C, st).reshape(B, HW, C) if split else dfeat.cpu().numpy()
+    close(got, np.einsum("bcf,hcf->bhc", d, ker.astype(np.float64)) * (feat > 0), what="sle dfeat")
     close(dker.cpu().numpy(), np.einsum("bhc,bcf->hcf", feat.astype(np.float64), d), what="sle dker")
 
 

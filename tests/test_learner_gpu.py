@@ -10,7 +10,7 @@ augmentation and indices bit-exact.
 The tight per-entry gradient bounds hold at matmul precision "highest" (exact fp32 MFMA).  At the default
 "bf16_3x" (each product accurate to ~2^-17) a pre-activation within ~1e-5 of zero can land on the other side
 of a ReLU, which moves single gradient entries by a whole term; gradients are then bounded per leaf in relative
-L2 norm (1e-2; 3e-2 after several Adam steps) and by 5e-2 of the leaf's max magnitude.  Losses / Q / entropy / temperature at "bf16_3x": rel 1e-3
+L2 norm (2e-2; 3e-2 after several Adam steps) and by 5e-2 of the leaf's max magnitude.  Losses / Q / entropy / temperature at "bf16_3x": rel 1e-3
 for every update() call with one critic step, started from the product's own state (the oracle is re-synchronised
 before each call), rel 5e-3 when the call holds several Adam steps (UTD > 1): Adam's sign-like first steps turn a
 1e-6 gradient difference into a +-lr parameter difference, so two correct implementations separate at that rate.
@@ -42,7 +42,7 @@ def _check_grads(agent, name, ref64, ref32, prec, rtol, noise_ref=None):
             assert_tree_close(got, ref32, rtol=rtol, what=name)
     else:
         ref = ref64 if noise_ref is not None else ref32
-        assert_tree_close(got, ref, rtol=5e-2, l2_rtol=1e-2 if noise_ref is not None else 3e-2, what=name)
+        assert_tree_close(got, ref, rtol=5e-2, l2_rtol=2e-2 if noise_ref is not None else 3e-2, what=name)
 
 
 @pytest.mark.parametrize("cfgname", ["sac_c1", "rlpd_u1", "rlpd_c2", "redq_m3"])

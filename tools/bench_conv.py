@@ -11,6 +11,7 @@ from serl_amd import ops  # noqa: E402
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 ONLY = os.environ.get("BENCH_ONLY", "")        # e.g. "conv3 fwd,conv2 dgrad": run only these launches
 NITER = int(os.environ.get("BENCH_N", "20"))
+MODE = os.environ.get("BENCH_MODE", "s")         # "s": S-format entry points (serl_convs_*); "f": serl_conv2d_*
 dev = torch.device("cuda")
 LAYERS = [(128, 9, 32), (63, 32, 64), (31, 64, 128), (15, 128, 256)]   # IH, C, F  (3x3, stride 2)
 st = ops.current_stream()
@@ -44,7 +45,32 @@ for li, (IH, C, F) in enumerate(LAYERS):
         ys = [torch.empty((B, OH, OH, F), device=dev) for _ in range(G)]
         dz = [torch.randn((B, OH, OH, F), device=dev) for _ in range(G)]
         p = lambda ts: [t.data_ptr() for t in ts]
-        if what == "fwd":
+
+        def to_s(t, rows, cols):
+            buf = torch.empty(rows * cols * 2, dtype=torch.int16, device=dev)
+            ops.split_f32(t.data_ptr(), buf.data_ptr(), rows, cols, st)
+            return buf
+        if MODE == "s":
+            u8 = li == 0
+            xS = xs if u8 else [to_s(x, B * IH * IH, C) for x in xs]
+            dzS = [to_s(z, B * OH * OH, F) for z in dz]
+            wb = ops.convs_weight_bytes(u8, 3, 3, C, F)
+            wf = [torch.empty(wb // 2, dtype=torch.int16, device=dev) for _ in range(G)]
+            wd = [torch.empty(9 * C * F * 2, dtype=torch.int16, device=dev) for _ in range(G)]
+            ops.convs_prep_weights(p(ws), p(wf), p(wd), u8, 3, 3, C, F, st)
+            yS = [torch.empty(B * OH * OH * F * 2, dtype=torch.int16, device=dev) for _ in range(G)]
+            if what == "fwd":
+                fn = lambda: ops.convs_fwd(p(xS), p(wf), p(bs), p(yS), u8, B, IH, IH, C, 3, 3, 2, F, True, st)
+            elif what == "wgrad":
+                nb = ops.conv2d_wgrad_workspace_bytes(G, B, IH, IH, C, 3, 3, 2, F)
+                wk = torch.empty(nb // 4, device=dev)
+                dws = [torch.empty_like(w) for w in ws]
+                fn = lambda: ops.convs_wgrad(p(xS), p(dzS), p(dws), p(bs), wk.data_ptr(), nb, u8, B, IH, IH, C, 3, 3,
+                                             2, F, st)
+            else:
+                dxS = [torch.empty(B * IH * IH * C * 2, dtype=torch.int16, device=dev) for _ in range(G)]
+                fn = lambda: ops.convs_dgrad(p(dzS), p(wd), p(xS), p(dxS), B, IH, IH, C, 3, 3, 2, F, st)
+        elif what == "fwd":
             fn = lambda: ops.conv2d_fwd(p(xs), p(ws), p(bs), p(ys), li == 0, B, IH, IH, C, 3, 3, 2, F, True, st)
         elif what == "wgrad":
             nb = ops.conv2d_wgrad_workspace_bytes(G, B, IH, IH, C, 3, 3, 2, F)

@@ -17,8 +17,8 @@ acc=collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("gpurun_out/pmc_$TAG/p*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         n=r['Kernel_Name']
-        if 'igemm' not in n: continue
-        n=n.replace('igemm_kernel','IG').replace('igemm_bf3_kernel','BF3').replace('TileCfg','T')[:60]
+        if 'gemm_kernel' not in n and 'igemm' not in n: continue
+        n=n.replace('igemm_kernel','IG').replace('sgemm_kernel','SG').replace('igemm_bf3_kernel','BF3').replace('TileCfg','T')[:60]
         acc[n][r['Counter_Name']].append(float(r['Counter_Value']))
 for n,c in acc.items():
     print(n)
