@@ -65,10 +65,11 @@ int serl_convs_wgrad(int ngroups, const void* const* x, const void* const* dz, f
                      int KW, int stride, int F, void* stream);
 
 /* ---- SpatialLearnedEmbeddings, serl/networks/spatial.py:13-27 (F must be 8) */
-int serl_sle_fwd(const void* feat, const float* ker, float* out, int ldo, int B, int HW, int C, int F, int feat_split,
-                 void* stream);
-int serl_sle_bwd(const float* dout, int ldo, const float* ker, const void* feat, void* dfeat, float* dker, int B,
+int serl_sle_fwd(int ngroups, const void* const* feat, const float* const* ker, float* const* out, int ldo, int B,
                  int HW, int C, int F, int feat_split, void* stream);
+int serl_sle_bwd(int ngroups, const float* const* dout, int ldo, const float* const* ker, const void* const* feat,
+                 void* const* dfeat, float* const* dker, int B, int HW, int C, int F, int feat_split, void* stream);
+/* Grouped like the convolutions (<= 8 groups = cameras x passes per launch); dfeat / dker may be NULL tables. */
 /* feat_split != 0: feat / dfeat are S-format tensors (below) instead of fp32. */
 
 /* ---- batched / segmented dense GEMM: nn.Dense of serl/networks/mlp.py:21-25, pixel_multiplexer.py:34,39, the

@@ -43,8 +43,8 @@ _SIGS = {
     "serl_actor_loss": [c_p, c_i, c_i, c_p, c_p, c_p, c_p],
     "serl_adam_polyak": [c_p, c_p, c_p, c_p, c_p, c_ll, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p],
     "serl_temperature_update": [c_p, c_p, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p, c_p],
-    "serl_sle_fwd": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
-    "serl_sle_bwd": [c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
+    "serl_sle_fwd": [c_i, PP, PP, PP, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
+    "serl_sle_bwd": [c_i, PP, c_i, PP, PP, PP, PP, c_i, c_i, c_i, c_i, c_i, c_p],
     "serl_convs_weight_bytes": [c_i] * 5,
     "serl_split_f32": [c_p, c_p, c_ll, c_i, c_p],
     "serl_merge_split": [c_p, c_p, c_ll, c_i, c_p],

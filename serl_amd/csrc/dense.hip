@@ -79,6 +79,10 @@ struct GemmP {
 
 typedef TileCfg<64, 64, 16, 2, 2> T64x64;
 typedef TileCfg<128, 128, 16, 2, 2> T128x128;
+// bf16_3x: the learner's dense GEMMs are 16..160 blocks of a long K loop, i.e. bound by the latency of one
+// K-step (~1 us: global -> LDS -> MFMA); a 64-deep slab makes 4x fewer of them.
+typedef TileCfg<64, 64, 64, 2, 2> B64x64;
+typedef TileCfg<128, 128, 32, 2, 2> B128x128;
 
 // layout codes: a_kcontig = 1 when consecutive k of A are adjacent in memory (else consecutive m are),
 //               b_ncontig = 1 when consecutive n of B are adjacent (else consecutive k are).
@@ -98,7 +102,7 @@ extern "C" int serl_gemm(const float* a, const float* b, float* c, const float* 
   g.c_zs = c_zs; g.c_ss = c_split_stride; g.c_ms = c_ms; g.bias_zs = bias_zs;
   g.relu = relu; g.accumulate = accumulate;
   g.d_seg = make_fastdiv(seglen);
-  int klen = cdiv(cdiv(K, nsplit), 16) * 16;
+  int klen = cdiv(cdiv(K, nsplit), 16) * 16;   // (slabs of the bf16_3x kernel may end inside a K-step: masked)
   g.klen = klen;
   const int ns = cdiv(K, klen);
   SERL_CHECK_ARG(ns == nsplit, "gemm: nsplit %d does not tile K=%d in multiples of 16 (got %d)", nsplit, K, ns);
@@ -113,8 +117,8 @@ extern "C" int serl_gemm(const float* a, const float* b, float* c, const float* 
 #define GO2(AK, BN, VA, VB)                                                                                \
   {                                                                                                         \
     GemmP<AK, BN, VA, VB> p; p.g = g;                                                                       \
-    return big ? igemm_launch_prec<GemmP<AK, BN, VA, VB>, T128x128>(p, M, N, nsplit, nbatch, st, "gemm")         \
-               : igemm_launch_prec<GemmP<AK, BN, VA, VB>, T64x64>(p, M, N, nsplit, nbatch, st, "gemm");          \
+    return big ? igemm_launch_prec<GemmP<AK, BN, VA, VB>, T128x128, B128x128>(p, M, N, nsplit, nbatch, st, "gemm") \
+               : igemm_launch_prec<GemmP<AK, BN, VA, VB>, T64x64, B64x64>(p, M, N, nsplit, nbatch, st, "gemm");  \
   }
 #define GO(AK, BN)                     \
   {                                    \

@@ -19,6 +19,9 @@
 #pragma once
 #include "igemm_bf3.h"
 
+#ifndef SG_DEPTH
+#define SG_DEPTH 2   // K-steps of register prefetch (1 or 2)
+#endif
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));   // native vector: stays in registers (HIP's uint4 struct does not)
 
@@ -43,8 +46,11 @@ constexpr int s_rc_stride(int rows) { return ((2 * rows - 64 + 127) / 128) * 128
 //   RC operand: a_row(ctx, m, ARow&) per 8-row chunk (m % 8 == 0), a_k(ctx, k, kend, AK&) per k;
 //   a_ptr(ctx, ARow, AK, const char*& hi, const char*& lo [, int& shift for A_U8]) -- always-valid addresses
 //   (zero page when out of range); same for b_*;  epilogue members as in igemm.h.
+#ifndef SG_MIN_WAVES
+#define SG_MIN_WAVES 2
+#endif
 template <class P, class T>
-__global__ __launch_bounds__(256, 2) void sgemm_kernel(const P p) {
+__global__ __launch_bounds__(256, SG_MIN_WAVES) void sgemm_kernel(const P p) {
   constexpr int BM = T::BM, BN = T::BN, BK = T::BK, TM = T::TM, TN = T::TN;
   static_assert(BK == 16 || BK == 32, "K slab");
   constexpr bool AKC = P::A_KC, BKC = P::B_KC, ALO = P::A_LO, BLO = P::B_LO, AU8 = P::A_U8;
@@ -230,6 +236,23 @@ __global__ __launch_bounds__(256, 2) void sgemm_kernel(const P p) {
   };
   constexpr std::integral_constant<int, 0> S0{};
   constexpr std::integral_constant<int, 1> S1{};
+#if SG_DEPTH == 1
+  gload(S0, kbeg);
+  lstore(S0, 0);
+  __syncthreads();
+  {
+    int cur = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+      gload(S0, k0 + BK);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(cur);
+      __builtin_amdgcn_sched_barrier(0);
+      lstore(S0, cur ^ 1);
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+#else
   // Loads and LDS writes are unconditional (a step past kend reads the zero page into a buffer nobody multiplies):
   // with straight-line code hipcc counts vmcnt exactly, so writing set t+1 does not drain the loads of t+2.
   gload(S0, kbeg);
@@ -254,6 +277,7 @@ __global__ __launch_bounds__(256, 2) void sgemm_kernel(const P p) {
     lstore(S0, cur);
     __syncthreads();
   }
+#endif
   igemm_epilogue<P, T>(p, ctx, acc, M, N, m0, n0, wm, wn, r, h, split);
 }
 

@@ -45,8 +45,8 @@ def _ksplit(K):
     """Split-K factor for the skinny (M = batch) trunk GEMM so that >= ~256 blocks are in flight."""
     if K < 1024:
         return 1
-    n = 16
-    while n > 1 and (K + n - 1) // n < 64:
+    n = 8
+    while n > 1 and (K + n - 1) // n < 256:
         n //= 2
     klen = ((K + n - 1) // n + 15) // 16 * 16
     return (K + klen - 1) // klen
@@ -90,12 +90,12 @@ def encoder_fwd(cfg: NetConfig, passes, B, ws: Workspace, st):
                 ops.conv2d_fwd(xs, wsp, bsp, ys, li == 0, B, L.IH, L.IW, L.C, L.K, L.K, L.S, L.F, True, st)
             xs = ys
     last = layers[-1]
-    for tag, store, ci, _ in groups:
-        enc = ws.ptr(f"enc_{tag}", (B, cfg.enc_dim))
-        feat = ws.ptr(f"act{nl - 1}_{tag}_{ci}", (B, last.OH, last.OW, last.F))
-        ops.sle_fwd(feat, store.ptr("image_encoder", f"SpatialLearnedEmbeddings_{ci}", "kernel"),
-                    enc + 4 * ci * last.F * SLE_FEATURES, cfg.enc_dim, B, last.OH * last.OW, last.F, SLE_FEATURES, st,
-                    feat_split=split)
+    for g0 in range(0, len(groups), 8):
+        chunk = groups[g0:g0 + 8]
+        ops.sle_fwd([ws.ptr(f"act{nl - 1}_{tag}_{ci}", (B, last.OH, last.OW, last.F)) for tag, _, ci, _ in chunk],
+                    [store.ptr("image_encoder", f"SpatialLearnedEmbeddings_{ci}", "kernel") for _, store, ci, _ in chunk],
+                    [ws.ptr(f"enc_{tag}", (B, cfg.enc_dim)) + 4 * ci * last.F * SLE_FEATURES for tag, _, ci, _ in chunk],
+                    cfg.enc_dim, B, last.OH * last.OW, last.F, SLE_FEATURES, st, feat_split=split)
 
 
 def encoder_bwd(cfg: NetConfig, tag, store, grads, imgs, B, ws: Workspace, st):
@@ -105,13 +105,13 @@ def encoder_bwd(cfg: NetConfig, tag, store, grads, imgs, B, ws: Workspace, st):
     last = layers[-1]
     split = split_conv_stack(cfg)      # same decision as the forward that filled act* / wd* for this tag
     denc = ws.ptr(f"denc_{tag}", (B, cfg.enc_dim))
-    for ci in range(ncam):
-        feat = ws.ptr(f"act{nl - 1}_{tag}_{ci}", (B, last.OH, last.OW, last.F))
-        dfeat = ws.ptr(f"dact{nl - 1}_{ci}", (B, last.OH, last.OW, last.F))
-        ops.sle_bwd(denc + 4 * ci * last.F * SLE_FEATURES, cfg.enc_dim,
-                    store.ptr("image_encoder", f"SpatialLearnedEmbeddings_{ci}", "kernel"), feat, dfeat,
-                    grads.ptr("image_encoder", f"SpatialLearnedEmbeddings_{ci}", "kernel"),
-                    B, last.OH * last.OW, last.F, SLE_FEATURES, st, feat_split=split)
+    cams = range(ncam)
+    ops.sle_bwd([denc + 4 * ci * last.F * SLE_FEATURES for ci in cams], cfg.enc_dim,
+                [store.ptr("image_encoder", f"SpatialLearnedEmbeddings_{ci}", "kernel") for ci in cams],
+                [ws.ptr(f"act{nl - 1}_{tag}_{ci}", (B, last.OH, last.OW, last.F)) for ci in cams],
+                [ws.ptr(f"dact{nl - 1}_{ci}", (B, last.OH, last.OW, last.F)) for ci in cams],
+                [grads.ptr("image_encoder", f"SpatialLearnedEmbeddings_{ci}", "kernel") for ci in cams],
+                B, last.OH * last.OW, last.F, SLE_FEATURES, st, feat_split=split)
     slab_bytes = max(ops.conv2d_wgrad_workspace_bytes(ncam, B, L.IH, L.IW, L.C, L.K, L.K, L.S, L.F) for L in layers)
     slab = ws.ptr("wgrad_slab", (slab_bytes // 4,))
     for li in range(nl - 1, -1, -1):
@@ -197,7 +197,7 @@ def ensemble_fwd(cfg: NetConfig, tag, store, m0, mstride, E, inp_ptr, ld_inp, B,
         bias = store.ptr(*pre, "MLP_0", f"Dense_{i}", "bias") + 4 * m0 * h
         hbuf = ws.ptr(f"h{i}_{tag}", (E, B, h))
         if ln:
-            pbuf = ws.ptr(f"epre{i}", (E, B, h))
+            pbuf = ws.ptr(f"epre{i}_{tag}", (E, B, h))   # per tag: the shape differs between passes (E)
             ops.gemm(a_ptr, W, pbuf, None, E, B, h, din, a_zs=a_zs, a_ms=a_ms, a_ks=1, b_zs=mstride * din * h,
                      b_ks=h, b_ns=1, c_zs=B * h, c_ms=h, stream=st)
             ops.ln_act_fwd(pbuf, 1, 0, h, bias, store.ptr(*pre, "MLP_0", f"LayerNorm_{i}", "scale") + 4 * m0 * h,

@@ -210,12 +210,26 @@ def temperature_update(state, sum_logp, inv_batch, target_entropy, lr, b1, b2, e
          float(b2), float(eps), float(bc1), float(bc2), info_out, stream)
 
 
-def sle_fwd(feat, ker, out, ldo, B, HW, C, F, stream, feat_split=False):
-    call("serl_sle_fwd", feat, ker, out, ldo, B, HW, C, F, int(feat_split), stream)
+def _as_list(x):
+    return list(x) if isinstance(x, (list, tuple)) else [x]
 
 
-def sle_bwd(dout, ldo, ker, feat, dfeat, dker, B, HW, C, F, stream, feat_split=False):
-    call("serl_sle_bwd", dout, ldo, ker, feat, dfeat, dker, B, HW, C, F, int(feat_split), stream)
+def sle_fwd(feats, kers, outs, ldo, B, HW, C, F, stream, feat_split=False):
+    """Grouped: feats / kers / outs are equally long lists of pointers (a single pointer = one group)."""
+    feats, kers, outs = _as_list(feats), _as_list(kers), _as_list(outs)
+    pf, kf = ptr_table(feats); pk, kk = ptr_table(kers); po, ko = ptr_table(outs)
+    call("serl_sle_fwd", len(feats), pf, pk, po, ldo, B, HW, C, F, int(feat_split), stream)
+
+
+def sle_bwd(douts, ldo, kers, feats, dfeats, dkers, B, HW, C, F, stream, feat_split=False):
+    douts, kers, feats = _as_list(douts), _as_list(kers), _as_list(feats)
+    pd, kd = ptr_table(douts); pk, kk = ptr_table(kers); pf, kf = ptr_table(feats)
+    pdf = pdk = None
+    if dfeats is not None:
+        pdf, kdf = ptr_table(_as_list(dfeats))
+    if dkers is not None:
+        pdk, kdk = ptr_table(_as_list(dkers))
+    call("serl_sle_bwd", len(douts), pd, ldo, pk, pf, pdf, pdk, B, HW, C, F, int(feat_split), stream)
 
 
 def gather_crop_frames(frames, cap, indx, T, t0, off, out, n, H, W, S, pad, stream):
