@@ -36,7 +36,8 @@ template <int BM_, int BN_, int BK_, int WGM_, int WGN_>
 struct TileCfg {
   static constexpr int BM = BM_, BN = BN_, BK = BK_, WGM = WGM_, WGN = WGN_;
   static constexpr int TM = BM_ / WGM_ / 32, TN = BN_ / WGN_ / 32;
-  static_assert(WGM_ * WGN_ == 4, "4 waves per block");
+  static constexpr int NT = 64 * WGM_ * WGN_;   // threads per block (igemm.h / igemm_bf3.h kernels: 4 waves only)
+  static_assert(WGM_ * WGN_ == 4 || WGM_ * WGN_ == 8, "4 or 8 waves per block");
   static_assert(TM * 32 * WGM_ == BM_ && TN * 32 * WGN_ == BN_, "tile/wave mismatch");
   static_assert((BM_ * BK_) % 256 == 0 && (BN_ * BK_) % 256 == 0, "load mapping");
 };
@@ -100,6 +101,7 @@ __device__ __forceinline__ void igemm_epilogue(const P& p, const typename P::Ctx
 //   void store(ctx, ORow, OCol, n, split, float v, float aux).
 template <class P, class T>
 __global__ __launch_bounds__(256, IGEMM_MIN_WAVES) void igemm_kernel(const P p) {
+  static_assert(T::NT == 256, "igemm_kernel runs 4 waves");
   constexpr int BM = T::BM, BN = T::BN, BK = T::BK, TM = T::TM, TN = T::TN;
   constexpr int LDA = BM + 4, LDB = BN + 4;
   __shared__ float As[2 * BK * LDA];

@@ -34,6 +34,7 @@ template <class P, class T>
 __global__ __launch_bounds__(256, 2) void igemm_bf3_kernel(const P p) {
   constexpr int BM = T::BM, BN = T::BN, BK = T::BK, TM = T::TM, TN = T::TN;
   static_assert(BK % 16 == 0, "bf16 MFMA consumes K in steps of 16");
+  static_assert(T::NT == 256, "igemm_bf3_kernel runs 4 waves");
   constexpr int VA = P::VA, VB = P::VB;
   constexpr bool AKC = P::A_KCONTIG, BKC = !P::B_NCONTIG;          // operand is k-contiguous in memory
   constexpr int LDKW = (BK + 8) / 2;                                 // dwords per row of a k-contiguous image

@@ -50,7 +50,8 @@ constexpr int s_rc_stride(int rows) { return ((2 * rows - 64 + 127) / 128) * 128
 #define SG_MIN_WAVES 2
 #endif
 template <class P, class T>
-__global__ __launch_bounds__(256, SG_MIN_WAVES) void sgemm_kernel(const P p) {
+__global__ __launch_bounds__(T::NT, SG_MIN_WAVES) void sgemm_kernel(const P p) {
+  constexpr int NT = T::NT;
   constexpr int BM = T::BM, BN = T::BN, BK = T::BK, TM = T::TM, TN = T::TN;
   static_assert(BK == 16 || BK == 32, "K slab");
   constexpr bool AKC = P::A_KC, BKC = P::B_KC, ALO = P::A_LO, BLO = P::B_LO, AU8 = P::A_U8;
@@ -81,11 +82,11 @@ __global__ __launch_bounds__(256, SG_MIN_WAVES) void sgemm_kernel(const P p) {
 
   // ---- chunk slots of this thread
   constexpr int A_DIV = AKC ? BK / 8 : BM / 8;          // chunks along the fast axis of the thread map
-  constexpr int A_STEP = 256 / A_DIV;
+  constexpr int A_STEP = NT / A_DIV;
   constexpr int A_EXT = AKC ? BM : BK;
   constexpr int NA = (A_EXT + A_STEP - 1) / A_STEP;
   constexpr int B_DIV = BKC ? BK / 8 : BN / 8;
-  constexpr int B_STEP = 256 / B_DIV;
+  constexpr int B_STEP = NT / B_DIV;
   constexpr int B_EXT = BKC ? BN : BK;
   constexpr int NB = (B_EXT + B_STEP - 1) / B_STEP;
   const int a_f = (tid % A_DIV) * 8, a_s = tid / A_DIV;   // fast-axis element offset, slow-axis index
@@ -303,7 +304,7 @@ static inline int sgemm_launch(const P& p, int max_m, int max_n, int nsplit, int
     opted[dev] = true;
   }
   dim3 grid(tiles, nsplit, nz);
-  hipLaunchKernelGGL((sgemm_kernel<P, T>), grid, dim3(256), lds, st, p);
+  hipLaunchKernelGGL((sgemm_kernel<P, T>), grid, dim3(T::NT), lds, st, p);
   SERL_CHECK_LAUNCH(name);
   return SERL_OK;
 }
