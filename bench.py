@@ -30,6 +30,8 @@ AGENT_KW = dict(cnn_features=(32, 64, 128, 256), cnn_filters=(3, 3, 3, 3), cnn_s
                 num_qs=10, num_min_qs=2, critic_layer_norm=True, backup_entropy=False, init_temperature=0.1,
                 hidden_dims=(256, 256), discount=0.99, tau=0.005)
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA (no sparsity)
+PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 FLOP_PER_GRAD_STEP = 304e9        # 301 critic + 3.1 amortised actor (2 FLOP / MAC)
 
 
@@ -67,6 +69,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--precision", default="bf16_3x", choices=["bf16_3x", "highest"],
+                    help="serl_amd.set_matmul_precision: bf16_3x (default of the library) or highest (exact fp32 MFMA)")
     args = ap.parse_args()
 
     import torch
@@ -74,6 +78,9 @@ def main():
     from serl_amd import ops
     from serl_amd.agents import DrQLearner
     from serl_amd.data import MemoryEfficientReplayBuffer
+    import serl_amd
+    serl_amd.set_matmul_precision(args.precision)
+    precision = serl_amd.get_matmul_precision()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -128,31 +135,48 @@ def main():
     value = grad_steps * world / elapsed
     roofline = None
     if timer is not None:
+        # dominant kernel = the conv launch configuration with the largest total time in the timed region; its
+        # roof is the larger of the two lower bounds: algorithmic HBM bytes / 8 TB/s, and MFMA work
+        # / dense peak (bf16_3x: 3 bf16 MFMA flops per algorithmic flop at 2500 TFLOP/s; highest: fp32 MFMA).
         summ = timer.summary()
-        key = max(summ, key=lambda k: summ[k][0] * summ[k][1])       # largest total time
-        n, ms, flops = summ[key]
-        achieved = flops / (ms * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "kernel": f"igemm {key[0]} (u8_in={key[1]}, groups={key[2]}, B={key[3]}, "
-                                               f"IH={key[4]}, C={key[5]}, F={key[6]})",
-                    "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
-                    "launches_timed": n, "avg_launch_ms": round(ms, 4),
-                    "all_conv_kernels": {f"{k[0]}|u8={k[1]}|g={k[2]}|IH={k[4]}|C={k[5]}|F={k[6]}":
-                                         {"launches": v[0], "avg_ms": round(v[1], 4),
-                                          "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 2)} for k, v in summ.items()}}
+        key = max(summ, key=lambda k: summ[k][0] * summ[k][1])
+        bf3 = precision == "bf16_3x"
+        mfma_peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if bf3 else PEAK_FP32_MFMA_TFLOPS
+
+        def roof(v):
+            n, ms, flops, byts = v
+            t_mfma, t_hbm = flops / (mfma_peak * 1e12), byts / (PEAK_HBM_GBS * 1e9)
+            if t_hbm >= t_mfma:
+                ach = byts / (ms * 1e-3) / 1e9
+                return {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": round(ach / PEAK_HBM_GBS, 4)}
+            ach = flops / (ms * 1e-3) / 1e12
+            return {"bound": "mfma", "achieved": round(ach, 2), "peak": round(mfma_peak, 1), "unit": "TFLOP/s",
+                    "frac": round(ach / mfma_peak, 4)}
+        n, ms, flops, byts = summ[key]
+        roofline = roof(summ[key])
+        roofline.update({
+            "kernel": f"{key[0]} (u8_in={key[1]}, groups={key[2]}, B={key[3]}, IH={key[4]}, C={key[5]}, F={key[6]})",
+            "traffic": None, "launches_timed": n, "avg_launch_ms": round(ms, 4),
+            "algorithmic_bytes_per_launch": byts, "algorithmic_flops_per_launch": flops,
+            "mfma_peak_note": "2500 TFLOP/s dense bf16 / 3 MFMAs per product block" if bf3 else "fp32 MFMA",
+            "all_conv_kernels": {f"{k[0]}|u8={k[1]}|g={k[2]}|IH={k[4]}|C={k[5]}|F={k[6]}":
+                                 dict(roof(v), launches=v[0], avg_ms=round(v[1], 4),
+                                      tflops=round(v[2] / (v[1] * 1e-3) / 1e12, 2),
+                                      gbs=round(v[3] / (v[1] * 1e-3) / 1e9, 1)) for k, v in summ.items()}})
     out = {
         "metric": "learner grad-steps/sec, DrQ-RLPD 128^2 pixels, batch 256, 10 critics, UTD 20",
         "value": round(value, 3), "unit": "grad-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32" if precision == "highest" else "bf16_3x", "data": "synthetic",
         "config": {"workload": "DrQ-RLPD update(): 2 cams 128x128x3 uint8, frame stack 3, conv encoder 32-64-128-256 "
                                "stride 2, 10 LayerNorm critics / 2 subsampled targets, UTD 20, 50/50 demo tail mixing, "
                                "HBM-resident MemoryEfficientReplayBuffer",
                    "batch_per_gpu": BATCH, "global_batch": BATCH * world, "utd": UTD,
                    "step_definition": "1 step = 1 update() call = 20 critic grad-steps + 1 actor/temperature step",
                    "value_definition": "grad-steps/s x global_batch/256", "parallelism": f"dp{world}"},
+        "matmul_precision": precision,
         "model_tflops": round(value * FLOP_PER_GRAD_STEP / 1e12, 2),
-        "frac_of_fp32_mfma_ceiling": round(value * FLOP_PER_GRAD_STEP / 1e12 / (PEAK_FP32_MFMA_TFLOPS * world), 4),
         "host_index_sampling_ms_per_update": round(sample_ms, 2),
         "last_info": {k: round(float(v), 5) for k, v in info.items()},
     }

@@ -21,19 +21,37 @@ class KernelTimer:
     def __init__(self):
         self.records = {}
 
-    def bracket(self, key, flops):
+    def bracket(self, key, cost):
         import torch
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        self.records.setdefault(key, []).append((a, b, flops))
+        self.records.setdefault(key, []).append((a, b, cost))
         return a, b
 
     def summary(self):
-        """key -> (launches, mean ms, flops per launch); call after a device synchronize."""
+        """key -> (launches, mean ms, algorithmic flops per launch, algorithmic HBM bytes per launch);
+        call after a device synchronize."""
         out = {}
         for key, recs in self.records.items():
             ms = [a.elapsed_time(b) for a, b, _ in recs]
-            out[key] = (len(ms), sum(ms) / len(ms), recs[0][2])
+            out[key] = (len(ms), sum(ms) / len(ms), recs[0][2][0], recs[0][2][1])
         return out
+
+
+def conv_cost(kind, in_u8, n, B, IH, IW, C, KH, KW, stride, F):
+    """Algorithmic (flops, HBM bytes) of one grouped conv launch: every tensor is read or
+    written once; activations and gradients are 4 bytes per element in either format, uint8 pixels 1 byte."""
+    OH, OW = (IH - KH) // stride + 1, (IW - KW) // stride + 1
+    flops = 2.0 * n * B * OH * OW * F * KH * KW * C
+    x = n * B * IH * IW * C * (1 if in_u8 else 4)
+    y = n * B * OH * OW * F * 4
+    w = n * KH * KW * C * F * 4
+    if kind == "fwd":
+        byts = x + w + y + n * F * 4
+    elif kind == "dgrad":       # reads dz, w and the ReLU mask (2-byte hi plane of x), writes dx
+        byts = y + w + x // 2 + x
+    else:                       # wgrad: reads x and dz, writes dw + dbias (split-K slabs stay in L2 / MALL)
+        byts = x + y + w + n * F * 4
+    return flops, float(byts)
 
 
 TIMER = None   # set to a KernelTimer to enable
@@ -44,8 +62,8 @@ def conv2d_fwd(xs, ws, bs, ys, in_u8, B, IH, IW, C, KH, KW, stride, F, relu, str
     px, kx = ptr_table(xs); pw, kw = ptr_table(ws); pb, kb = ptr_table(bs); py, ky = ptr_table(ys)
     ev = None
     if TIMER is not None:
-        OH, OW = (IH - KH) // stride + 1, (IW - KW) // stride + 1
-        ev = TIMER.bracket(("conv2d_fwd", bool(in_u8), n, B, IH, C, F), 2.0 * n * B * OH * OW * F * KH * KW * C)
+        ev = TIMER.bracket(("conv2d_fwd", bool(in_u8), n, B, IH, C, F),
+                           conv_cost("fwd", bool(in_u8), n, B, IH, IW, C, KH, KW, stride, F))
         ev[0].record()
     call("serl_conv2d_fwd", n, px, pw, pb, py, int(in_u8), B, IH, IW, C, KH, KW, stride, F, int(relu), stream)
     if ev is not None:
@@ -57,8 +75,8 @@ def conv2d_dgrad(dzs, ws, xacts, dxs, B, IH, IW, C, KH, KW, stride, F, stream):
     pz, kz = ptr_table(dzs); pw, kw = ptr_table(ws); pa, ka = ptr_table(xacts); pd, kd = ptr_table(dxs)
     ev = None
     if TIMER is not None:
-        OH, OW = (IH - KH) // stride + 1, (IW - KW) // stride + 1
-        ev = TIMER.bracket(("conv2d_dgrad", False, n, B, IH, C, F), 2.0 * n * B * OH * OW * F * KH * KW * C)
+        ev = TIMER.bracket(("conv2d_dgrad", False, n, B, IH, C, F),
+                           conv_cost("dgrad", False, n, B, IH, IW, C, KH, KW, stride, F))
         ev[0].record()
     call("serl_conv2d_dgrad", n, pz, pw, pa, pd, B, IH, IW, C, KH, KW, stride, F, stream)
     if ev is not None:
@@ -107,8 +125,8 @@ def convs_fwd(xs, wfs, bs, ys, in_u8, B, IH, IW, C, KH, KW, stride, F, relu, str
     px, kx = ptr_table(xs); pw, kw = ptr_table(wfs); pb, kb = ptr_table(bs); py, ky = ptr_table(ys)
     ev = None
     if TIMER is not None:
-        OH, OW = (IH - KH) // stride + 1, (IW - KW) // stride + 1
-        ev = TIMER.bracket(("convs_fwd", bool(in_u8), n, B, IH, C, F), 2.0 * n * B * OH * OW * F * KH * KW * C)
+        ev = TIMER.bracket(("convs_fwd", bool(in_u8), n, B, IH, C, F),
+                           conv_cost("fwd", bool(in_u8), n, B, IH, IW, C, KH, KW, stride, F))
         ev[0].record()
     call("serl_convs_fwd", n, px, pw, pb, py, int(in_u8), B, IH, IW, C, KH, KW, stride, F, int(relu), stream)
     if ev is not None:
@@ -120,8 +138,8 @@ def convs_dgrad(dzs, wds, xacts, dxs, B, IH, IW, C, KH, KW, stride, F, stream):
     pz, kz = ptr_table(dzs); pw, kw = ptr_table(wds); pa, ka = ptr_table(xacts); pd, kd = ptr_table(dxs)
     ev = None
     if TIMER is not None:
-        OH, OW = (IH - KH) // stride + 1, (IW - KW) // stride + 1
-        ev = TIMER.bracket(("convs_dgrad", False, n, B, IH, C, F), 2.0 * n * B * OH * OW * F * KH * KW * C)
+        ev = TIMER.bracket(("convs_dgrad", False, n, B, IH, C, F),
+                           conv_cost("dgrad", False, n, B, IH, IW, C, KH, KW, stride, F))
         ev[0].record()
     call("serl_convs_dgrad", n, pz, pw, pa, pd, B, IH, IW, C, KH, KW, stride, F, stream)
     if ev is not None:
@@ -133,8 +151,8 @@ def convs_wgrad(xs, dzs, dws, dbs, workspace, workspace_bytes, in_u8, B, IH, IW,
     px, kx = ptr_table(xs); pz, kz = ptr_table(dzs); pw, kw = ptr_table(dws); pb, kb = ptr_table(dbs)
     ev = None
     if TIMER is not None:
-        OH, OW = (IH - KH) // stride + 1, (IW - KW) // stride + 1
-        ev = TIMER.bracket(("convs_wgrad", bool(in_u8), n, B, IH, C, F), 2.0 * n * B * OH * OW * F * KH * KW * C)
+        ev = TIMER.bracket(("convs_wgrad", bool(in_u8), n, B, IH, C, F),
+                           conv_cost("wgrad", bool(in_u8), n, B, IH, IW, C, KH, KW, stride, F))
         ev[0].record()
     call("serl_convs_wgrad", n, px, pz, pw, pb, workspace, workspace_bytes, int(in_u8), B, IH, IW, C, KH, KW,
          stride, F, stream)
