@@ -23,25 +23,31 @@ static int make_geom(ConvGeom& g, int B, int IH, int IW, int C, int KH, int KW, 
   return SERL_OK;
 }
 
-// out[g][e] = sum_s slab[g][s][e]; rows < KKC go to dW, the last row to dbias. 64 elements x 4 s-lanes.
+// out[g][e] = sum_s slab[g][s][e]; rows < KKC go to dW, the last row to dbias. 16 elements x 16 slab lanes.
 struct ReduceArgs {
   const float* slab; float* dw[MAXG]; float* db[MAXG];
   int nsplit, kkc, F;
 };
 static __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const ReduceArgs a) {
-  __shared__ float part[4][64];
+  // 16 elements x 16 slab lanes per block; lane sl sums slabs sl, sl+16, ... (independent loads in flight),
+  // then the 16 partials are added in a fixed order.
+  __shared__ float part[16][17];
   const int gi = blockIdx.y;
   const int nel = (a.kkc + 1) * a.F;
-  const int el = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int sl = threadIdx.x >> 6;
+  const int e = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int el = blockIdx.x * 16 + e;
   const float* base = a.slab + (size_t)gi * a.nsplit * (size_t)nel;
   float s = 0.f;
-  if (el < nel)
-    for (int k = sl; k < a.nsplit; k += 4) s += base[(size_t)k * nel + el];
-  part[sl][threadIdx.x & 63] = s;
+  if (el < nel) {
+#pragma unroll 8
+    for (int k = sl; k < a.nsplit; k += 16) s += base[(size_t)k * nel + el];
+  }
+  part[sl][e] = s;
   __syncthreads();
   if (sl == 0 && el < nel) {
-    const float v = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v += part[k][e];
     if (el < a.kkc * a.F) a.dw[gi][el] = v;
     else a.db[gi][el - a.kkc * a.F] = v;
   }

@@ -313,24 +313,39 @@ struct PrepArgs {
   int KH, KWC, F, Kp, pad32;
 };
 __global__ __launch_bounds__(256) void prep_weights_kernel(const PrepArgs a) {
-  const int gi = blockIdx.y;
-  const int i = blockIdx.x * 256 + threadIdx.x;      // over Kp * F, f fastest
-  if (i >= a.Kp * a.F) return;
-  const int kp = i / a.F, f = i - kp * a.F;
-  int k = kp;
-  bool valid = true;
-  if (a.pad32) {
-    const int ky = kp >> 5, j = kp & 31;
-    valid = j < a.KWC;
-    k = ky * a.KWC + j;
+  // tile = 32 k' x 32 f: read and the wd write run along f, the wf write runs along k' (transposed through LDS)
+  __shared__ unsigned short th[32][33], tl[32][33];
+  const int gi = blockIdx.z;
+  const int kp0 = blockIdx.x * 32, f0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int kp = kp0 + ty + 8 * i, f = f0 + tx;
+    int k = kp;
+    bool valid = kp < a.Kp && f < a.F;
+    if (a.pad32) {
+      const int ky = kp >> 5, j = kp & 31;
+      valid = valid && j < a.KWC;
+      k = ky * a.KWC + j;
+    }
+    ushort_t h = 0, l = 0;
+    if (valid) {
+      split1(a.w[gi][(size_t)k * a.F + f], h, l);
+      if (a.wd[gi] != nullptr) {
+        a.wd[gi][(size_t)(k * 2) * a.F + f] = h;
+        a.wd[gi][(size_t)(k * 2 + 1) * a.F + f] = l;
+      }
+    }
+    th[ty + 8 * i][tx] = h; tl[ty + 8 * i][tx] = l;
   }
-  ushort_t h = 0, l = 0;
-  if (valid) split1(a.w[gi][(size_t)k * a.F + f], h, l);
-  a.wf[gi][(size_t)(f * 2) * a.Kp + kp] = h;
-  a.wf[gi][(size_t)(f * 2 + 1) * a.Kp + kp] = l;
-  if (valid && a.wd[gi] != nullptr) {
-    a.wd[gi][(size_t)(k * 2) * a.F + f] = h;
-    a.wd[gi][(size_t)(k * 2 + 1) * a.F + f] = l;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int f = f0 + ty + 8 * i, kp = kp0 + tx;
+    if (f < a.F && kp < a.Kp) {
+      a.wf[gi][(size_t)(f * 2) * a.Kp + kp] = th[tx][ty + 8 * i];
+      a.wf[gi][(size_t)(f * 2 + 1) * a.Kp + kp] = tl[tx][ty + 8 * i];
+    }
   }
 }
 
@@ -386,7 +401,7 @@ extern "C" int serl_convs_prep_weights(int ngroups, const float* const* w, void*
     SERL_CHECK_ARG(w[i] && wf[i], "convs_prep_weights: null pointer");
     a.w[i] = w[i]; a.wf[i] = (ushort_t*)wf[i]; a.wd[i] = wd ? (ushort_t*)wd[i] : nullptr;
   }
-  hipLaunchKernelGGL(prep_weights_kernel, dim3(cdiv(a.Kp * F, 256), ngroups), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(prep_weights_kernel, dim3(cdiv(a.Kp, 32), cdiv(F, 32), ngroups), dim3(256), 0, (hipStream_t)stream, a);
   SERL_CHECK_LAUNCH("convs_prep_weights");
   return SERL_OK;
 }
@@ -470,7 +485,7 @@ extern "C" int serl_convs_wgrad(int ngroups, const void* const* x, const void* c
   if (e) return e;
   ReduceArgs ra; ra.slab = workspace; ra.nsplit = nsplit; ra.kkc = kkc; ra.F = F;
   for (int i = 0; i < ngroups; ++i) { ra.dw[i] = dw[i]; ra.db[i] = dbias[i]; }
-  dim3 grid(cdiv((kkc + 1) * F, 64), ngroups);
+  dim3 grid(cdiv((kkc + 1) * F, 16), ngroups);
   hipLaunchKernelGGL(wgrad_reduce_kernel, grid, dim3(256), 0, st, ra);
   SERL_CHECK_LAUNCH("wgrad_reduce");
   return SERL_OK;

@@ -36,7 +36,9 @@ __global__ __launch_bounds__(256) void ln_act_fwd_kernel(const LnFwdArgs a) {
     const int n = lane + 64 * i;
     float v = 0.f;
     if (n < a.N) {
-      for (int s = 0; s < a.nslab; ++s) v += a.pre[s * a.pre_ss + (long long)row * a.ldpre + n];
+      const float* src = a.pre + (long long)row * a.ldpre + n;
+#pragma unroll 8   // the slab loads are independent: issue them together (a rolled loop pays one round trip each)
+      for (int s = 0; s < a.nslab; ++s) v += src[s * a.pre_ss];
       if (bias) v += bias[n];
     }
     z[i] = v;
@@ -162,7 +164,7 @@ extern "C" int serl_ln_act_bwd(const float* dy, int lddy, const float* dq, const
 // ------------------------------------------------------------------ column reductions over the batch
 // out_k[e][n] = sum_{r in group e} term_k[r][n], fixed summation order (reproducible):
 //   k=0: x0[r][n] * (w ? w[r] : 1) * (mul ? mul[r][n] : 1)      k=1: x1[r][n]      k=2: x2[r][n] * mul2[r][n]
-// Block = 32 columns x 8 row lanes; each row lane walks rows rl, rl+8, ...
+// Block = 16 columns x 16 row lanes; each row lane walks rows rl, rl+16, ... (unrolled: independent loads in flight)
 struct ColSumArgs {
   const float* x0; const float* w; const float* mul; float* out0;
   const float* x1; float* out1;
@@ -170,12 +172,13 @@ struct ColSumArgs {
   int rows_per_group, N, ldx; long long out_gs;
 };
 __global__ __launch_bounds__(256) void colsum_kernel(const ColSumArgs a) {
-  __shared__ float red[3][8][33];
-  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
-  const int n = blockIdx.x * 32 + cl, e = blockIdx.y;
+  __shared__ float red[3][16][17];
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int n = blockIdx.x * 16 + cl, e = blockIdx.y;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f;
   if (n < a.N) {
-    for (int r = rl; r < a.rows_per_group; r += 8) {
+#pragma unroll 4
+    for (int r = rl; r < a.rows_per_group; r += 16) {
       const long long row = (long long)e * a.rows_per_group + r;
       const long long i = row * a.ldx + n;
       float v = a.x0[i];
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const ColSumArgs a) {
   if (rl < 3 && n < a.N) {
     float s = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) s += red[rl][k][cl];
+    for (int k = 0; k < 16; ++k) s += red[rl][k][cl];
     float* out = rl == 0 ? a.out0 : (rl == 1 ? a.out1 : a.out2);
     if (out) out[e * a.out_gs + n] = s;
   }
@@ -204,7 +207,7 @@ extern "C" int serl_colsum(const float* x0, const float* w, const float* mul, fl
   SERL_CHECK_ARG((x1 != nullptr) == (out1 != nullptr), "colsum: x1/out1 mismatch");
   SERL_CHECK_ARG((x2 != nullptr) == (out2 != nullptr) && (!x2 || mul2), "colsum: x2/mul2/out2 mismatch");
   ColSumArgs a{x0, w, mul, out0, x1, out1, x2, mul2, out2, rows_per_group, N, ldx, out_group_stride};
-  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 32), ngroups), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 16), ngroups), dim3(256), 0, (hipStream_t)stream, a);
   SERL_CHECK_LAUNCH("colsum");
   return SERL_OK;
 }

@@ -260,8 +260,16 @@ def ensemble_bwd(cfg: NetConfig, tag, store, grads, dq_ptr, inp_ptr, ld_inp, B, 
                      c_zs=B * hp, c_ms=hp, b_ncontig=False, stream=st)
         else:
             dinp = ws.ptr("dinp", (B, hp))
-            ops.gemm(dz, W, dinp, None, 1, B, hp, E * h, seglen=h, a_ss=B * h, a_ms=h, a_ks=1, b_ss=hp * h, b_ks=1,
-                     b_ns=h, c_ms=hp, b_ncontig=False, stream=st)
+            ns = _ksplit(E * h)          # few (M, N) tiles and a long K = (member, feature) loop: split it
+            if ns > 1:
+                slab = ws.ptr("dinp_slab", (ns, B, hp))
+                ops.gemm(dz, W, slab, None, 1, B, hp, E * h, seglen=h, a_ss=B * h, a_ms=h, a_ks=1, b_ss=hp * h, b_ks=1,
+                         b_ns=h, c_ms=hp, b_ncontig=False, nsplit=ns, c_split_stride=B * hp, stream=st)
+                ops.ln_act_fwd(slab, ns, B * hp, hp, None, None, None, 0, dinp, hp, None, None, B, hp, B, False,
+                               ops.ACT_NONE, st)
+            else:
+                ops.gemm(dz, W, dinp, None, 1, B, hp, E * h, seglen=h, a_ss=B * h, a_ms=h, a_ks=1, b_ss=hp * h, b_ks=1,
+                         b_ns=h, c_ms=hp, b_ncontig=False, stream=st)
             return dinp
 
 
