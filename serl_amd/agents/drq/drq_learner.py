@@ -107,7 +107,7 @@ class DrQLearner(SACLearner):
     def _prepare(self, batch, n):
         raise RuntimeError("DrQLearner prepares features inside update()")
 
-    def _features(self, passes, feats, lo, B, ws, st, save_tag=None):
+    def _features(self, passes, feats, lo, B, ws, st, save_tag=None, trunk_streams=None, fork=None):
         cfg = self._cfg
         ldz = cfg.latent + cfg.action_dim
         img_bytes = cfg.H * cfg.W * 3 * cfg.stack
@@ -116,10 +116,15 @@ class DrQLearner(SACLearner):
             imgs = [feats["aug"][which][cam].data_ptr() + lo * img_bytes for cam in cfg.cams]
             enc_passes.append((tag, store, imgs))
         nn.encoder_fwd(cfg, enc_passes, B, ws, st)
+        if fork is not None:          # the trunks of the passes are independent: side streams wait for the encoders
+            fork.record(torch.cuda.current_stream())
+            for s_ in trunk_streams.values():
+                s_.wait_event(fork)
         for tag, store, which in passes:
             state = feats["next_state" if which == "next" else "state"]
+            st_ = trunk_streams[tag].cuda_stream if trunk_streams and tag in trunk_streams else st
             nn.trunk_fwd(cfg, tag, store, state.data_ptr() + 4 * lo * cfg.state_dim, ws.ptr(f"z{tag}", (B, ldz)), ldz,
-                         B, ws, st, save=(tag == save_tag))
+                         B, ws, st_, save=(tag == save_tag))
 
     def _features_bwd(self, tag, store, grads, feats, lo, B, ws, st, dz_ptr, lddz, need_encoder):
         cfg = self._cfg

@@ -100,6 +100,16 @@ class SACLearner(Agent):
             g = self._shared[name] = like.zeros_like()
         return g
 
+    def _side_streams(self):
+        """Two side HIP streams + reusable events: the target and critic forward chains of a critic step are
+        independent of the actor chain until the TD target, and each is a string of small latency-bound launches."""
+        ss = self._shared.get("side_streams")
+        if ss is None:
+            ss = self._shared["side_streams"] = dict(
+                s=[torch.cuda.Stream(), torch.cuda.Stream()],
+                fork=torch.cuda.Event(), join=[torch.cuda.Event(), torch.cuda.Event()])
+        return ss
+
     def _target_members(self, key):
         """REDQ subsample (serl/networks/ensemble.py:25-37) -> (first member, member stride, count)."""
         E = self.num_qs
@@ -136,14 +146,21 @@ class SACLearner(Agent):
         return dict(obs=_to_dev(batch["observations"], dev, f32).reshape(n, -1),
                     next_obs=_to_dev(batch["next_observations"], dev, f32).reshape(n, -1))
 
-    def _features(self, passes, feats, lo, B, ws, st, save_tag=None):
-        """passes: list of (tag, store, which) -> fills z_<tag>[:, :latent]. State-based: a strided copy."""
+    def _features(self, passes, feats, lo, B, ws, st, save_tag=None, trunk_streams=None, fork=None):
+        """passes: list of (tag, store, which) -> fills z_<tag>[:, :latent]. State-based: a strided copy.
+        trunk_streams: {tag: torch stream} for passes whose per-pass work may run on a side stream; `fork` is
+        the event the side streams wait on (recorded here, after everything they depend on)."""
+        if fork is not None:
+            fork.record(torch.cuda.current_stream())
+            for s_ in trunk_streams.values():
+                s_.wait_event(fork)
         cfg = self._cfg
         ldz = cfg.latent + cfg.action_dim
         for tag, _store, which in passes:
             src = feats["next_obs" if which == "next" else "obs"]
+            st_ = trunk_streams[tag].cuda_stream if trunk_streams and tag in trunk_streams else st
             ops.copy2d(ws.ptr(f"z{tag}", (B, ldz)), ldz, src.data_ptr() + 4 * lo * cfg.obs_dim, cfg.obs_dim, B,
-                       cfg.obs_dim, st)
+                       cfg.obs_dim, st_)
 
     def _features_bwd(self, tag, store, grads, feats, lo, B, ws, st, dz_ptr, lddz, need_encoder):
         return  # no trainable feature stage for state inputs
@@ -194,13 +211,23 @@ class SACLearner(Agent):
             tstore = target.store
             if m0 is None:
                 tstore, m0, mstride = self._gathered_target(idx, target.store), 0, 1
+            # encoders of the three passes in grouped launches on the main stream, then three concurrent chains:
+            #   main: actor trunk + policy (next action -> zT)      side 0: target trunk      side 1: critic trunk + Q
+            ss = self._side_streams()
+            main = torch.cuda.current_stream()
+            s0, s1 = ss["s"]
             self._features([("A", actor.store, "next"), ("T", target.store, "next"), ("C", critic.store, "obs")],
-                           feats, lo, B, ws, st, save_tag="C")
+                           feats, lo, B, ws, st, save_tag="C", trunk_streams={"T": s0, "C": s1}, fork=ss["fork"])
             nlogp = nn.policy_fwd(cfg, "A", actor.store, zA, ldz, B, ws, st, key_act, rank * B, Bg,
                                   zT + 4 * cfg.latent, ldz, want_logp=self.backup_entropy)
+            ss["join"][0].record(s0)
+            main.wait_event(ss["join"][0])
             next_q = nn.ensemble_fwd(cfg, "T", tstore, m0, mstride, emin, zT, ldz, B, ws, st, save=False)
-            ops.copy2d(zC + 4 * cfg.latent, ldz, actions.data_ptr() + 4 * lo * A, A, B, A, st)
-            q = nn.ensemble_fwd(cfg, "C", critic.store, 0, 1, E, zC, ldz, B, ws, st, save=True)
+            st1 = s1.cuda_stream
+            ops.copy2d(zC + 4 * cfg.latent, ldz, actions.data_ptr() + 4 * lo * A, A, B, A, st1)
+            q = nn.ensemble_fwd(cfg, "C", critic.store, 0, 1, E, zC, ldz, B, ws, st1, save=True)
+            ss["join"][1].record(s1)
+            main.wait_event(ss["join"][1])
             dq = ws.ptr("dq", (E, B))
             ops.td_loss(next_q, emin, rewards.data_ptr() + 4 * lo, masks.data_ptr() + 4 * lo,
                         nlogp if self.backup_entropy else None, log_temp, self.discount, q, E, B, 1.0 / (E * Bg),

@@ -31,6 +31,9 @@ class Workspace:
         shape = tuple(int(s) for s in shape)
         if t is None or tuple(t.shape) != shape or t.dtype != dtype:
             t = torch.zeros(shape, dtype=dtype, device=self.device)
+            # the zero fill runs on torch's current stream; kernels that use the buffer may run on a side stream
+            # (sac_learner._side_streams): make the fill visible everywhere. Only on first use of a name/shape.
+            torch.cuda.synchronize(self.device)
             self._t[name] = t
         return t
 
