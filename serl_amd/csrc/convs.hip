@@ -24,7 +24,7 @@ __device__ __forceinline__ void split1(float v, ushort_t& hi, ushort_t& lo) {
 // B: KC, rows = output channels, from wf = S-format [F][2][Kp] (k order as A)
 template <bool U8>
 struct ConvFwdS {
-  static constexpr bool A_KC = true, B_KC = true, A_LO = !U8, B_LO = true, A_U8 = U8;
+  static constexpr bool A_KC = true, B_KC = true, A_LO = !U8, B_LO = true, A_U8 = U8, S_OUT = true;
   ConvGeom g;
   int Kp;
   float scale;                      // 1/255 for uint8 input, else 1
@@ -89,6 +89,20 @@ struct ConvFwdS {
     hi = ok ? (const char*)(c.wf + n.base + k.off) : zero_page();
     lo = hi + 2 * Kp;
   }
+  struct SCol { float b[8]; };
+  __device__ void s_col(const Ctx& c, int n, SCol& s) const {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s.b[j] = c.bias[n + j];
+  }
+  __device__ void s_finish(const Ctx&, const ORow&, const SCol& s, int, float (&v)[8]) const {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      v[j] = fmaf(v[j], scale, s.b[j]);
+      if (relu) v[j] = fmaxf(v[j], 0.f);
+    }
+  }
+  __device__ ushort_t* s_out(const Ctx& c) const { return c.y; }
+  __device__ size_t s_base(const ORow& o) const { return o.base; }
   __device__ void o_col(const Ctx& c, int n, OCol& o) const { o.bias = c.bias[n]; }
   __device__ void o_row(const Ctx&, int m, ORow& o) const { o.base = (uint32_t)m * 2 * g.F; }
   __device__ float o_aux(const Ctx&, const ORow&, int, int) const { return 0.f; }
@@ -106,7 +120,7 @@ struct ConvFwdS {
 // per parity class of input pixels (conv.hip): A: KC, rows = input pixels of the class, k = (tap, f) from dz (S);
 // B: KC, rows = input channels, from wd = S-format of the HWIO kernel viewed as [(ky,kx,c)][2][F].
 struct ConvDgradS {
-  static constexpr bool A_KC = true, B_KC = true, A_LO = true, B_LO = true, A_U8 = false;
+  static constexpr bool A_KC = true, B_KC = true, A_LO = true, B_LO = true, A_U8 = false, S_OUT = true;
   ConvGeom g;
   int G;
   const ushort_t* dz[MAXG];
@@ -181,6 +195,19 @@ struct ConvDgradS {
     const uint32_t iyp = fd_div(rem, c.d_w), ixp = rem - iyp * c.IWc;
     o.base = ((b * g.IH + iyp * g.S + c.py) * g.IW + ixp * g.S + c.px) * 2 * g.C;
   }
+  struct SCol {};
+  __device__ void s_col(const Ctx&, int, SCol&) const {}
+  __device__ void s_finish(const Ctx& c, const ORow& o, const SCol&, int n, float (&v)[8]) const {
+    if (c.xact == nullptr) return;
+    const u32x4_t m = *reinterpret_cast<const u32x4_t*>(c.xact + o.base + n);     // hi plane of the post-ReLU input
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (!(m[j] & 0x7fffu)) v[2 * j] = 0.f;
+      if (!(m[j] & 0x7fff0000u)) v[2 * j + 1] = 0.f;
+    }
+  }
+  __device__ ushort_t* s_out(const Ctx& c) const { return c.dx; }
+  __device__ size_t s_base(const ORow& o) const { return o.base; }
   __device__ void o_col(const Ctx&, int, OCol&) const {}
   __device__ float o_aux(const Ctx& c, const ORow& o, int n, int) const {
     if (c.xact == nullptr) return 1.f;
@@ -199,7 +226,7 @@ struct ConvDgradS {
 // B: RC, rows = output channels, k = output pixels, from dz (S).  Output: fp32 slabs as in conv.hip.
 template <bool U8>
 struct ConvWgradS {
-  static constexpr bool A_KC = false, B_KC = false, A_LO = !U8, B_LO = true, A_U8 = U8;
+  static constexpr bool A_KC = false, B_KC = false, A_LO = !U8, B_LO = true, A_U8 = U8, S_OUT = false;
   ConvGeom g;
   FastDiv d_c, d_kw;
   const void* x[MAXG];

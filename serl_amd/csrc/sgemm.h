@@ -45,7 +45,20 @@ constexpr int s_rc_stride(int rows) { return ((2 * rows - 64 + 127) / 128) * 128
 //   KC operand: a_row(ctx, m, ARow&) per row, a_k(ctx, k, kend, AK&) per chunk (k % 8 == 0);
 //   RC operand: a_row(ctx, m, ARow&) per 8-row chunk (m % 8 == 0), a_k(ctx, k, kend, AK&) per k;
 //   a_ptr(ctx, ARow, AK, const char*& hi, const char*& lo [, int& shift for A_U8]) -- always-valid addresses
-//   (zero page when out of range); same for b_*;  epilogue members as in igemm.h.
+//   (zero page when out of range); same for b_*;  epilogue members as in igemm.h, or with S_OUT = true:
+//   SCol + s_col(ctx, n, SCol&) (per 8-column context, e.g. bias), s_finish(ctx, ORow, SCol, n, float v[8]) (bias /
+//   activation / mask on 8 consecutive columns), s_out(ctx) (ushort* of the S-format output), s_base(ORow) (ushort
+//   offset of the row's record: hi plane at base + n, lo plane at base + N + n).
+template <class P, class T>
+constexpr int sgemm_lds_bytes() {
+  constexpr int KC_STRIDE = (T::BK + 8) * 2;
+  constexpr int A_PLANE = P::A_KC ? T::BM * KC_STRIDE : T::BK * s_rc_stride(T::BM);
+  constexpr int B_PLANE = P::B_KC ? T::BN * KC_STRIDE : T::BK * s_rc_stride(T::BN);
+  constexpr int stage = 2 * ((P::A_LO ? 2 : 1) * A_PLANE + (P::B_LO ? 2 : 1) * B_PLANE);
+  constexpr int epi = P::S_OUT ? T::BM * (T::BN + 4) * 4 : 0;       // fp32 tile of the S-format epilogue
+  return stage > epi ? stage : epi;
+}
+
 #ifndef SG_MIN_WAVES
 #define SG_MIN_WAVES 2
 #endif
@@ -279,15 +292,55 @@ __global__ __launch_bounds__(T::NT, SG_MIN_WAVES) void sgemm_kernel(const P p) {
     __syncthreads();
   }
 #endif
-  igemm_epilogue<P, T>(p, ctx, acc, M, N, m0, n0, wm, wn, r, h, split);
-}
-
-template <class P, class T>
-constexpr int sgemm_lds_bytes() {
-  constexpr int KC_STRIDE = (T::BK + 8) * 2;
-  constexpr int A_PLANE = P::A_KC ? T::BM * KC_STRIDE : T::BK * s_rc_stride(T::BM);
-  constexpr int B_PLANE = P::B_KC ? T::BN * KC_STRIDE : T::BK * s_rc_stride(T::BN);
-  return 2 * ((P::A_LO ? 2 : 1) * A_PLANE + (P::B_LO ? 2 : 1) * B_PLANE);
+  if constexpr (P::S_OUT) {
+    // ---- S-format output through LDS: the accumulators (column on the lane, rows in registers) are laid out as an
+    // fp32 tile, then every thread finishes 8 consecutive channels of one row: bias / ReLU / mask, split into hi
+    // and lo, two 16-byte stores -- 8x fewer (and full-width) store instructions than one 2-byte store per element.
+    constexpr int LDC = BN + 4;
+    static_assert(BM * LDC * 4 <= sgemm_lds_bytes<P, T>(), "epilogue tile must fit the staging LDS");
+    float* Cs = reinterpret_cast<float*>(s_smem);
+    __syncthreads();                                   // everyone is done reading the last K-step's images
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int row = wm * (TM * 32) + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+          Cs[row * LDC + wn * (TN * 32) + j * 32 + r] = acc[i][j][q];
+        }
+    __syncthreads();
+    constexpr int CH = BN / 8, RPP = NT / CH;          // chunks per row, rows per pass
+    const int ch = tid % CH, rr = tid / CH;
+    const int n = n0 + ch * 8;
+    if (n < N) {
+      typename P::SCol sc;
+      p.s_col(ctx, n, sc);
+      unsigned short* out = p.s_out(ctx);
+#pragma unroll 2
+      for (int row = rr; row < BM; row += RPP) {
+        const int m = m0 + row;
+        if (m >= M) break;
+        typename P::ORow orow;
+        p.o_row(ctx, m, orow);
+        const float4 v0 = *reinterpret_cast<const float4*>(Cs + row * LDC + ch * 8);
+        const float4 v1 = *reinterpret_cast<const float4*>(Cs + row * LDC + ch * 8 + 4);
+        float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        p.s_finish(ctx, orow, sc, n, v);
+        u32x4_t hi, lo;
+        uint32_t hh, ll;
+        split_pair(v[0], v[1], hh, ll); hi[0] = hh; lo[0] = ll;
+        split_pair(v[2], v[3], hh, ll); hi[1] = hh; lo[1] = ll;
+        split_pair(v[4], v[5], hh, ll); hi[2] = hh; lo[2] = ll;
+        split_pair(v[6], v[7], hh, ll); hi[3] = hh; lo[3] = ll;
+        unsigned short* dst = out + p.s_base(orow) + n;
+        *reinterpret_cast<u32x4_t*>(dst) = hi;
+        *reinterpret_cast<u32x4_t*>(dst + N) = lo;
+      }
+    }
+  } else {
+    igemm_epilogue<P, T>(p, ctx, acc, M, N, m0, n0, wm, wn, r, h, split);
+  }
 }
 
 template <class P, class T>
