@@ -60,7 +60,7 @@ static void wgrad_plan(const ConvGeom& g, int ngroups, int& nsplit, int& klen) {
   const int tiles = cdiv(kkc1, 128) * cdiv(g.F, bn) * ngroups;
   int want = cdiv(1024, tiles);
   if (want < 1) want = 1;
-  klen = cdiv(cdiv(Kr, want), 32) * 32;   // multiple of both kernels' K slab
+  klen = cdiv(cdiv(Kr, want), 64) * 64;   // multiple of every kernel's K slab
   if (klen < 64) klen = 64;
   nsplit = cdiv(Kr, klen);
 }

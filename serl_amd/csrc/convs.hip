@@ -377,18 +377,29 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(const PrepArgs a) {
 }
 
 // ------------------------------------------------------------------------------ host API
-#ifndef CONVS_BK
-#define CONVS_BK 32
-#endif
-typedef TileCfg<128, 128, CONVS_BK, 2, 2> S128x128;
-typedef TileCfg<128, 64, CONVS_BK, 4, 2> S128x64;    // 8 waves: measured 8-25% faster than 4 waves of 64x32 on the 64-wide layers
-typedef TileCfg<128, 32, CONVS_BK, 4, 1> S128x32;
+// Tiles (measured per layer, tools/bench_conv.py): one LDS stage (two barriers per K-step, half the LDS, more blocks
+// per CU) wins everywhere except the 128-wide weight gradients; a 64-deep K slab (full 128-byte lines per row chunk)
+// wins where K is long, 32 on the first two forward layers (K = 96 / 288).
+typedef TileCfg<128, 128, 64, 2, 2> S128x128k64;
+typedef TileCfg<128, 128, 32, 2, 2> S128x128k32;
+typedef TileCfg<128, 64, 64, 4, 2> S128x64k64;      // 8 waves
+typedef TileCfg<128, 64, 32, 4, 2> S128x64k32;
+typedef TileCfg<128, 32, 64, 4, 1> S128x32k64;
+typedef TileCfg<128, 32, 32, 4, 1> S128x32k32;
 
+enum SKind { S_FWD, S_DGRAD, S_WGRAD };
 template <class P>
-static int s_launch_by_n(const P& p, int max_m, int n, int nsplit, int nz, hipStream_t st, const char* name) {
-  if (n <= 32) return sgemm_launch<P, S128x32>(p, max_m, n, nsplit, nz, st, name);
-  if (n <= 64) return sgemm_launch<P, S128x64>(p, max_m, n, nsplit, nz, st, name);
-  return sgemm_launch<P, S128x128>(p, max_m, n, nsplit, nz, st, name);
+static int s_launch_by_n(SKind kind, const P& p, int max_m, int n, int nsplit, int nz, hipStream_t st, const char* name) {
+  if (n <= 32) {
+    if (kind == S_FWD) return sgemm_launch<P, S128x32k32, 1>(p, max_m, n, nsplit, nz, st, name);
+    return sgemm_launch<P, S128x32k64, 1>(p, max_m, n, nsplit, nz, st, name);
+  }
+  if (n <= 64) {
+    if (kind == S_FWD) return sgemm_launch<P, S128x64k32, 1>(p, max_m, n, nsplit, nz, st, name);
+    return sgemm_launch<P, S128x64k64, 1>(p, max_m, n, nsplit, nz, st, name);
+  }
+  if (kind == S_WGRAD) return sgemm_launch<P, S128x128k32, 2>(p, max_m, n, nsplit, nz, st, name);
+  return sgemm_launch<P, S128x128k64, 1>(p, max_m, n, nsplit, nz, st, name);
 }
 
 static bool all_aligned16(const void* const* ps, int n) {
@@ -448,8 +459,8 @@ extern "C" int serl_convs_fwd(int ngroups, const void* const* x, const void* con
   p.g = g; p.relu = relu; p.Kp = s_kp(in_u8, KH, KW, C); p.scale = in_u8 ? 1.0f / 255.0f : 1.0f;             \
   p.d_c = make_fastdiv(C); p.d_kw = make_fastdiv(KW);                                                        \
   for (int i = 0; i < ngroups; ++i) { p.x[i] = x[i]; p.wf[i] = (const ushort_t*)wf[i]; p.bias[i] = bias[i]; p.y[i] = (ushort_t*)y[i]; }
-  if (in_u8) { ConvFwdS<true> p; FILL(p) return s_launch_by_n(p, M, F, 1, ngroups, st, "convs_fwd_u8"); }
-  ConvFwdS<false> p; FILL(p) return s_launch_by_n(p, M, F, 1, ngroups, st, "convs_fwd");
+  if (in_u8) { ConvFwdS<true> p; FILL(p) return s_launch_by_n(S_FWD, p, M, F, 1, ngroups, st, "convs_fwd_u8"); }
+  ConvFwdS<false> p; FILL(p) return s_launch_by_n(S_FWD, p, M, F, 1, ngroups, st, "convs_fwd");
 #undef FILL
 }
 
@@ -482,7 +493,7 @@ extern "C" int serl_convs_dgrad(int ngroups, const void* const* dz, const void* 
     p.xact[i] = xact ? (const ushort_t*)xact[i] : nullptr; p.dx[i] = (ushort_t*)dx[i];
   }
   const int max_m = g.B * cdiv(g.IH, stride) * cdiv(g.IW, stride);
-  return s_launch_by_n(p, max_m, g.C, 1, ngroups * stride * stride, (hipStream_t)stream, "convs_dgrad");
+  return s_launch_by_n(S_DGRAD, p, max_m, g.C, 1, ngroups * stride * stride, (hipStream_t)stream, "convs_dgrad");
 }
 
 extern "C" int serl_convs_wgrad(int ngroups, const void* const* x, const void* const* dz, float* const* dw,
@@ -506,8 +517,8 @@ extern "C" int serl_convs_wgrad(int ngroups, const void* const* x, const void* c
   p.Mp = in_u8 ? KH * 32 + 1 : kkc + 1; p.scale = in_u8 ? 1.0f / 255.0f : 1.0f;                        \
   p.d_c = make_fastdiv(C); p.d_kw = make_fastdiv(KW);                                                  \
   for (int i = 0; i < ngroups; ++i) { p.x[i] = x[i]; p.dz[i] = (const ushort_t*)dz[i]; }
-  if (in_u8) { ConvWgradS<true> p; FILLW(p) e = s_launch_by_n(p, p.Mp, F, nsplit, ngroups, st, "convs_wgrad_u8"); }
-  else { ConvWgradS<false> p; FILLW(p) e = s_launch_by_n(p, p.Mp, F, nsplit, ngroups, st, "convs_wgrad"); }
+  if (in_u8) { ConvWgradS<true> p; FILLW(p) e = s_launch_by_n(S_WGRAD, p, p.Mp, F, nsplit, ngroups, st, "convs_wgrad_u8"); }
+  else { ConvWgradS<false> p; FILLW(p) e = s_launch_by_n(S_WGRAD, p, p.Mp, F, nsplit, ngroups, st, "convs_wgrad"); }
 #undef FILLW
   if (e) return e;
   ReduceArgs ra; ra.slab = workspace; ra.nsplit = nsplit; ra.kkc = kkc; ra.F = F;

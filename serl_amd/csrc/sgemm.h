@@ -49,12 +49,12 @@ constexpr int s_rc_stride(int rows) { return ((2 * rows - 64 + 127) / 128) * 128
 //   SCol + s_col(ctx, n, SCol&) (per 8-column context, e.g. bias), s_finish(ctx, ORow, SCol, n, float v[8]) (bias /
 //   activation / mask on 8 consecutive columns), s_out(ctx) (ushort* of the S-format output), s_base(ORow) (ushort
 //   offset of the row's record: hi plane at base + n, lo plane at base + N + n).
-template <class P, class T>
+template <class P, class T, int LBUF>
 constexpr int sgemm_lds_bytes() {
   constexpr int KC_STRIDE = (T::BK + 8) * 2;
   constexpr int A_PLANE = P::A_KC ? T::BM * KC_STRIDE : T::BK * s_rc_stride(T::BM);
   constexpr int B_PLANE = P::B_KC ? T::BN * KC_STRIDE : T::BK * s_rc_stride(T::BN);
-  constexpr int stage = 2 * ((P::A_LO ? 2 : 1) * A_PLANE + (P::B_LO ? 2 : 1) * B_PLANE);
+  constexpr int stage = LBUF * ((P::A_LO ? 2 : 1) * A_PLANE + (P::B_LO ? 2 : 1) * B_PLANE);
   constexpr int epi = P::S_OUT ? T::BM * (T::BN + 4) * 4 : 0;       // fp32 tile of the S-format epilogue
   return stage > epi ? stage : epi;
 }
@@ -62,11 +62,12 @@ constexpr int sgemm_lds_bytes() {
 #ifndef SG_MIN_WAVES
 #define SG_MIN_WAVES 2
 #endif
-template <class P, class T>
+template <class P, class T, int LBUF>
 __global__ __launch_bounds__(T::NT, SG_MIN_WAVES) void sgemm_kernel(const P p) {
   constexpr int NT = T::NT;
   constexpr int BM = T::BM, BN = T::BN, BK = T::BK, TM = T::TM, TN = T::TN;
-  static_assert(BK == 16 || BK == 32, "K slab");
+  static_assert(BK == 16 || BK == 32 || BK == 64, "K slab");
+  static_assert(LBUF == 1 || LBUF == 2, "LDS stages: 2 = one barrier per K-step, 1 = two barriers, half the LDS");
   constexpr bool AKC = P::A_KC, BKC = P::B_KC, ALO = P::A_LO, BLO = P::B_LO, AU8 = P::A_U8;
   constexpr int KC_STRIDE = (BK + 8) * 2;                               // bytes per row of a KC image
   constexpr int A_STRIDE = AKC ? KC_STRIDE : s_rc_stride(BM);
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(T::NT, SG_MIN_WAVES) void sgemm_kernel(const P p) {
   constexpr int A_BUF = (ALO ? 2 : 1) * A_PLANE, B_BUF = (BLO ? 2 : 1) * B_PLANE;
   extern __shared__ __attribute__((aligned(16))) unsigned char s_smem[];
   unsigned char* const As = s_smem;                     // [buf][plane][...]
-  unsigned char* const Bs = s_smem + 2 * A_BUF;
+  unsigned char* const Bs = s_smem + LBUF * A_BUF;
 
   typename P::Ctx ctx;
   if (!p.init(ctx, blockIdx.z)) return;
@@ -250,6 +251,20 @@ __global__ __launch_bounds__(T::NT, SG_MIN_WAVES) void sgemm_kernel(const P p) {
   };
   constexpr std::integral_constant<int, 0> S0{};
   constexpr std::integral_constant<int, 1> S1{};
+  if constexpr (LBUF == 1) {
+  gload(S0, kbeg);
+  lstore(S0, 0);
+  __syncthreads();
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    gload(S0, k0 + BK);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    lstore(S0, 0);
+    __syncthreads();
+  }
+  } else {
 #if SG_DEPTH == 1
   gload(S0, kbeg);
   lstore(S0, 0);
@@ -292,12 +307,13 @@ __global__ __launch_bounds__(T::NT, SG_MIN_WAVES) void sgemm_kernel(const P p) {
     __syncthreads();
   }
 #endif
+  }
   if constexpr (P::S_OUT) {
     // ---- S-format output through LDS: the accumulators (column on the lane, rows in registers) are laid out as an
     // fp32 tile, then every thread finishes 8 consecutive channels of one row: bias / ReLU / mask, split into hi
     // and lo, two 16-byte stores -- 8x fewer (and full-width) store instructions than one 2-byte store per element.
     constexpr int LDC = BN + 4;
-    static_assert(BM * LDC * 4 <= sgemm_lds_bytes<P, T>(), "epilogue tile must fit the staging LDS");
+    static_assert(BM * LDC * 4 <= sgemm_lds_bytes<P, T, LBUF>(), "epilogue tile must fit the staging LDS");
     float* Cs = reinterpret_cast<float*>(s_smem);
     __syncthreads();                                   // everyone is done reading the last K-step's images
 #pragma unroll
@@ -343,21 +359,21 @@ __global__ __launch_bounds__(T::NT, SG_MIN_WAVES) void sgemm_kernel(const P p) {
   }
 }
 
-template <class P, class T>
+template <class P, class T, int LBUF = 2>
 static inline int sgemm_launch(const P& p, int max_m, int max_n, int nsplit, int nz, hipStream_t st, const char* name) {
   const int tiles = cdiv(max_m, T::BM) * cdiv(max_n, T::BN);
   if (tiles <= 0 || nsplit <= 0 || nz <= 0) return SERL_OK;
-  constexpr int lds = sgemm_lds_bytes<P, T>();
+  constexpr int lds = sgemm_lds_bytes<P, T, LBUF>();
   static_assert(lds <= 160 * 1024, "tile does not fit the 160 KB LDS");
   static bool opted[64] = {};
   int dev = 0;
   SERL_CHECK_HIP(hipGetDevice(&dev), name);
   if (lds > 48 * 1024 && dev >= 0 && dev < 64 && !opted[dev]) {
-    SERL_CHECK_HIP(hipFuncSetAttribute((const void*)sgemm_kernel<P, T>, hipFuncAttributeMaxDynamicSharedMemorySize, lds), name);
+    SERL_CHECK_HIP(hipFuncSetAttribute((const void*)sgemm_kernel<P, T, LBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds), name);
     opted[dev] = true;
   }
   dim3 grid(tiles, nsplit, nz);
-  hipLaunchKernelGGL((sgemm_kernel<P, T>), grid, dim3(T::NT), lds, st, p);
+  hipLaunchKernelGGL((sgemm_kernel<P, T, LBUF>), grid, dim3(T::NT), lds, st, p);
   SERL_CHECK_LAUNCH(name);
   return SERL_OK;
 }
