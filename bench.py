@@ -42,6 +42,24 @@ def fill_buffer(buf, n_transitions, seed):
         buf.insert(tr)
 
 
+def measured_traffic(key):
+    """HBM-side bytes per launch of a conv launch configuration, from the newest profiles/*_traffic.json
+    (tools/traffic.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 correction applied).
+    bench.py cannot collect PMC counters on itself; None when no measurement of this configuration is on file."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
+    if not files:
+        return None, None
+    kind, in_u8, groups, B, IH, C, F = key
+    layer = {H: 1, (H - 3) // 2 + 1: 2, ((H - 3) // 2 + 1 - 3) // 2 + 1: 3}.get(IH, 4)
+    op = f"conv{layer} {kind.split('_')[-1]}"
+    want_groups = 6 if op.endswith("fwd") else 2
+    if B != BATCH or groups != want_groups or not kind.startswith("convs_"):
+        return None, None
+    e = json.load(open(files[-1]))["launches"].get(op)
+    return (e["hbm_side_bytes"], os.path.basename(files[-1])) if e else (None, None)
+
+
 def cpu_baseline(seed=0):
     """CPU restatement (oracle, torch-CPU fp32 -- NOT JAX/XLA) on a bounded sample of the same workload:
     one update() call with UTD 16 at batch 256 (16 grad-steps + the actor/temperature step), ~10-20 s."""
@@ -155,9 +173,10 @@ def main():
                     "frac": round(ach / mfma_peak, 4)}
         n, ms, flops, byts = summ[key]
         roofline = roof(summ[key])
+        traffic, traffic_src = measured_traffic(key)
         roofline.update({
             "kernel": f"{key[0]} (u8_in={key[1]}, groups={key[2]}, B={key[3]}, IH={key[4]}, C={key[5]}, F={key[6]})",
-            "traffic": None, "launches_timed": n, "avg_launch_ms": round(ms, 4),
+            "traffic": traffic, "traffic_source": traffic_src, "launches_timed": n, "avg_launch_ms": round(ms, 4),
             "algorithmic_bytes_per_launch": byts, "algorithmic_flops_per_launch": flops,
             "mfma_peak_note": "2500 TFLOP/s dense bf16 / 3 MFMAs per product block" if bf3 else "fp32 MFMA",
             "all_conv_kernels": {f"{k[0]}|u8={k[1]}|g={k[2]}|IH={k[4]}|C={k[5]}|F={k[6]}":

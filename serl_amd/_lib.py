@@ -80,6 +80,9 @@ def load():
         raise SerlHipError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C serl_amd/csrc`). There is no CPU fallback.")
+    # torch first: it ships its own libamdhip64; loading ours first would pull a second HIP runtime (/opt/rocm)
+    # into the process, and kernels registered there see "no ROCm-capable device".
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, args in _SIGS.items():
         fn = getattr(lib, name)

@@ -1,23 +1,35 @@
 #!/bin/bash
-# usage: tools/traffic.sh <tag> ["conv3 fwd,..."]  -- HBM-side traffic of the conv launches (FETCH_SIZE / WRITE_SIZE, one pass each)
-TAG=$1; ONLY=$2
-CMD="mkdir -p gpurun_out/traffic_$TAG && cd /tmp && export TMPDIR=/tmp && export BENCH_ONLY='$ONLY' BENCH_N=2"
-for P in FETCH_SIZE WRITE_SIZE; do
-  CMD="$CMD && timeout -s KILL 120 rocprofv3 --pmc $P --output-format csv -d \$GRAFT_REPO_ROOT/gpurun_out/traffic_$TAG/$P -- python3 \$GRAFT_REPO_ROOT/tools/bench_conv.py > \$GRAFT_REPO_ROOT/gpurun_out/traffic_$TAG/$P.out 2>&1"
+# usage: tools/traffic.sh <out.json>  -- HBM-side traffic of every conv launch of the bench workload:
+# rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs (MI355X_MICROARCH.md, HBM section), one
+# launch configuration per run (tools/bench_conv.py, BENCH_ONLY), averaged over the dispatches of the run.
+OUT=$1
+OPS="conv1_fwd conv1_wgrad conv2_fwd conv2_wgrad conv2_dgrad conv3_fwd conv3_wgrad conv3_dgrad conv4_fwd conv4_wgrad conv4_dgrad"
+CMD="mkdir -p gpurun_out/traffic && cd /tmp && export TMPDIR=/tmp && export BENCH_N=2"
+for OP in $OPS; do
+  for P in FETCH_SIZE WRITE_SIZE; do
+    CMD="$CMD && BENCH_ONLY='${OP/_/ }' timeout -s KILL 120 rocprofv3 --pmc $P --output-format csv -d \$GRAFT_REPO_ROOT/gpurun_out/traffic/${OP}_$P -- python3 \$GRAFT_REPO_ROOT/tools/bench_conv.py > \$GRAFT_REPO_ROOT/gpurun_out/traffic/${OP}_$P.out 2>&1"
+  done
 done
-/usr/local/graft/bin/gpurun --timeout 600 -- "$CMD; tail -2 \$GRAFT_REPO_ROOT/gpurun_out/traffic_$TAG/WRITE_SIZE.out" 2>&1 | tail -4
-python3 - <<PY
-import csv,glob,collections
-acc=collections.defaultdict(lambda: collections.defaultdict(list))
-order=[]
-for f in glob.glob("gpurun_out/traffic_$TAG/*/*/*counter_collection.csv"):
-    for r in csv.DictReader(open(f)):
-        n=r['Kernel_Name']
-        if 'gemm_kernel' not in n: continue
-        key=(n.replace('sgemm_kernel','SG').replace('TileCfg','T')[:58], r['Grid_Size'] if 'Grid_Size' in r else '')
-        if key not in order: order.append(key)
-        acc[key][r['Counter_Name']].append(float(r['Counter_Value']))
-for key in order:
-    v={k:sum(x)/len(x) for k,x in acc[key].items()}
-    print(key[0], 'grid', key[1], ' FETCH_SIZE', v.get('FETCH_SIZE'), ' WRITE_SIZE', v.get('WRITE_SIZE'))
+rm -rf gpurun_out/traffic
+/usr/local/graft/bin/gpurun --timeout 1100 -- "$CMD; echo done" 2>&1 | tail -3
+python3 - "$OUT" <<'PY'
+import csv, glob, json, sys
+out = {}
+for d in sorted(glob.glob("gpurun_out/traffic/*_FETCH_SIZE")) + sorted(glob.glob("gpurun_out/traffic/*_WRITE_SIZE")):
+    op, counter = d.split("/")[-1].rsplit("_", 2)[0], "_".join(d.split("/")[-1].rsplit("_", 2)[1:])
+    vals, name = [], None
+    for f in glob.glob(d + "/*/*counter_collection.csv"):
+        for r in csv.DictReader(open(f)):
+            if "gemm_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                vals.append(float(r["Counter_Value"])); name = r["Kernel_Name"]
+    if vals:
+        e = out.setdefault(op.replace("_", " "), {"kernel": name})
+        e[counter + "_KB"] = sum(vals) / len(vals)
+for op, e in out.items():
+    # gfx950: FETCH_SIZE tallies the 128-byte requests of wide (16 B/lane) loads at 64 B -> double it; WRITE_SIZE is exact
+    e["hbm_side_bytes"] = 2 * 1024 * e.get("FETCH_SIZE_KB", 0) + 1024 * e.get("WRITE_SIZE_KB", 0)
+json.dump({"note": "L2-miss (fabric-side) bytes per launch: 2 x FETCH_SIZE + WRITE_SIZE (MI355X_MICROARCH.md gfx950 correction); "
+                   "Infinity-Cache hits are included; B=256, groups as in bench.py (fwd 6, wgrad/dgrad 2)", "launches": out},
+          open(sys.argv[1], "w"), indent=1)
+for op, e in out.items(): print(op, round(e["hbm_side_bytes"] / 1e6, 1), "MB")
 PY
