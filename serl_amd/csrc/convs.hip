@@ -24,7 +24,7 @@ __device__ __forceinline__ void split1(float v, ushort_t& hi, ushort_t& lo) {
 // B: KC, rows = output channels, from wf = S-format [F][2][Kp] (k order as A)
 template <bool U8>
 struct ConvFwdS {
-  static constexpr bool A_KC = true, B_KC = true, A_LO = !U8, B_LO = true, A_U8 = U8, S_OUT = true;
+  static constexpr bool A_KC = true, B_KC = true, A_LO = !U8, B_LO = true, A_U8 = U8, S_OUT = true, XCD_SWZ = false;
   ConvGeom g;
   int Kp;
   float scale;                      // 1/255 for uint8 input, else 1
@@ -120,7 +120,7 @@ struct ConvFwdS {
 // per parity class of input pixels (conv.hip): A: KC, rows = input pixels of the class, k = (tap, f) from dz (S);
 // B: KC, rows = input channels, from wd = S-format of the HWIO kernel viewed as [(ky,kx,c)][2][F].
 struct ConvDgradS {
-  static constexpr bool A_KC = true, B_KC = true, A_LO = true, B_LO = true, A_U8 = false, S_OUT = true;
+  static constexpr bool A_KC = true, B_KC = true, A_LO = true, B_LO = true, A_U8 = false, S_OUT = true, XCD_SWZ = false;
   ConvGeom g;
   int G;
   const ushort_t* dz[MAXG];
@@ -226,7 +226,7 @@ struct ConvDgradS {
 // B: RC, rows = output channels, k = output pixels, from dz (S).  Output: fp32 slabs as in conv.hip.
 template <bool U8>
 struct ConvWgradS {
-  static constexpr bool A_KC = false, B_KC = false, A_LO = !U8, B_LO = true, A_U8 = U8, S_OUT = false;
+  static constexpr bool A_KC = false, B_KC = false, A_LO = !U8, B_LO = true, A_U8 = U8, S_OUT = false, XCD_SWZ = true;
   ConvGeom g;
   FastDiv d_c, d_kw;
   const void* x[MAXG];
