@@ -162,7 +162,7 @@ class SACLearner(Agent):
             ops.copy2d(ws.ptr(f"z{tag}", (B, ldz)), ldz, src.data_ptr() + 4 * lo * cfg.obs_dim, cfg.obs_dim, B,
                        cfg.obs_dim, st_)
 
-    def _features_bwd(self, tag, store, grads, feats, lo, B, ws, st, dz_ptr, lddz, need_encoder):
+    def _features_bwd(self, tag, store, grads, feats, lo, B, ws, st, dz_ptr, lddz, need_encoder, gside=None):
         return  # no trainable feature stage for state inputs
 
     # ------------------------------------------------------------------ update
@@ -232,8 +232,13 @@ class SACLearner(Agent):
             ops.td_loss(next_q, emin, rewards.data_ptr() + 4 * lo, masks.data_ptr() + 4 * lo,
                         nlogp if self.backup_entropy else None, log_temp, self.discount, q, E, B, 1.0 / (E * Bg),
                         ws.ptr("target_q", (B,)), dq, info.data_ptr(), st)
-            dinp = nn.ensemble_bwd(cfg, "C", critic.store, cgr, dq, zC, ldz, B, ws, st)
-            self._features_bwd("C", critic.store, cgr, feats, lo, B, ws, st, dinp, ldz, need_encoder=True)
+            gside = self._shared.get("grad_side")
+            if gside is None:
+                gside = self._shared["grad_side"] = nn.GradSide()
+            gside.begin()
+            dinp = nn.ensemble_bwd(cfg, "C", critic.store, cgr, dq, zC, ldz, B, ws, st, gside=gside)
+            self._features_bwd("C", critic.store, cgr, feats, lo, B, ws, st, dinp, ldz, need_encoder=True, gside=gside)
+            gside.join()
             if dist is not None:
                 dist.all_reduce_sum(cgr.flat)
             critic.step += 1

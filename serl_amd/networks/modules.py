@@ -44,6 +44,39 @@ class Workspace:
         return sum(t.numel() * t.element_size() for t in self._t.values())
 
 
+class GradSide:
+    """Side stream for parameter-gradient kernels (column sums, dW GEMMs): they are only needed by the optimizer
+    step, so they leave the critical path dz -> dX -> dz of the backward chain.  fork() makes the side stream
+    wait for everything enqueued on the main stream so far and returns its handle; join() makes main wait."""
+
+    def __init__(self):
+        self.main = torch.cuda.current_stream()
+        self.side = torch.cuda.Stream()
+        self._ev = []
+        self._n = 0
+
+    def begin(self):
+        self.main = torch.cuda.current_stream()
+        self._n = 0
+
+    def fork(self) -> int:
+        if self._n == len(self._ev):
+            self._ev.append(torch.cuda.Event())
+        ev = self._ev[self._n]
+        self._n += 1
+        ev.record(self.main)
+        self.side.wait_event(ev)
+        return self.side.cuda_stream
+
+    def join(self):
+        if self._n == len(self._ev):
+            self._ev.append(torch.cuda.Event())
+        ev = self._ev[self._n]
+        self._n += 1
+        ev.record(self.side)
+        self.main.wait_event(ev)
+
+
 def _ksplit(K):
     """Split-K factor for the skinny (M = batch) trunk GEMM so that >= ~256 blocks are in flight."""
     if K < 1024:
@@ -163,28 +196,32 @@ def trunk_fwd(cfg: NetConfig, tag, store, state_ptr, z_ptr, ldz, B, ws: Workspac
                    B, Ld, B, True, TANH, st)
 
 
-def trunk_bwd(cfg: NetConfig, tag, store, grads, state_ptr, z_ptr, ldz, dz_ptr, lddz, B, ws: Workspace, st, need_denc):
+def trunk_bwd(cfg: NetConfig, tag, store, grads, state_ptr, z_ptr, ldz, dz_ptr, lddz, B, ws: Workspace, st, need_denc,
+              gside: "GradSide | None" = None):
     K, Ld, Sd = cfg.enc_dim, cfg.latent_dim, cfg.state_dim
+    stw = st            # stream of the parameter-gradient kernels
     dpre0 = ws.ptr("dpre0", (B, TRUNK_DIM)); g0 = ws.ptr("g0", (B, TRUNK_DIM))
     xh0 = ws.ptr(f"xhat0_{tag}", (B, TRUNK_DIM))
     ops.ln_act_bwd(dz_ptr, lddz, None, None, 0, z_ptr, ldz, xh0, ws.ptr(f"rstd0_{tag}", (B,)),
                    store.ptr("LayerNorm_0", "scale"), 0, dpre0, g0, B, TRUNK_DIM, B, True, TANH, st)
-    ops.colsum(g0, grads.ptr("LayerNorm_0", "bias"), 1, B, TRUNK_DIM, TRUNK_DIM, 0, st,
-               x1=dpre0, out1=grads.ptr("Dense_0", "bias"), x2=g0, mul2=xh0, out2=grads.ptr("LayerNorm_0", "scale"))
-    enc = ws.ptr(f"enc_{tag}", (B, K))
-    ops.gemm(enc, dpre0, grads.ptr("Dense_0", "kernel"), None, 1, K, TRUNK_DIM, B, a_ms=1, a_ks=K,
-             b_ks=TRUNK_DIM, b_ns=1, c_ms=TRUNK_DIM, a_kcontig=False, stream=st)
-    if need_denc:
-        ops.gemm(dpre0, store.ptr("Dense_0", "kernel"), ws.ptr(f"denc_{tag}", (B, K)), None, 1, B, K, TRUNK_DIM,
-                 a_ms=TRUNK_DIM, a_ks=1, b_ks=1, b_ns=TRUNK_DIM, c_ms=K, b_ncontig=False, stream=st)
     dpre1 = ws.ptr("dpre1", (B, Ld)); g1 = ws.ptr("g1", (B, Ld))
     xh1 = ws.ptr(f"xhat1_{tag}", (B, Ld))
     ops.ln_act_bwd(dz_ptr + 4 * TRUNK_DIM, lddz, None, None, 0, z_ptr + 4 * TRUNK_DIM, ldz, xh1,
                    ws.ptr(f"rstd1_{tag}", (B,)), store.ptr("LayerNorm_1", "scale"), 0, dpre1, g1, B, Ld, B, True, TANH, st)
-    ops.colsum(g1, grads.ptr("LayerNorm_1", "bias"), 1, B, Ld, Ld, 0, st,
+    if gside is not None:
+        stw = gside.fork()
+    ops.colsum(g0, grads.ptr("LayerNorm_0", "bias"), 1, B, TRUNK_DIM, TRUNK_DIM, 0, stw,
+               x1=dpre0, out1=grads.ptr("Dense_0", "bias"), x2=g0, mul2=xh0, out2=grads.ptr("LayerNorm_0", "scale"))
+    enc = ws.ptr(f"enc_{tag}", (B, K))
+    ops.gemm(enc, dpre0, grads.ptr("Dense_0", "kernel"), None, 1, K, TRUNK_DIM, B, a_ms=1, a_ks=K,
+             b_ks=TRUNK_DIM, b_ns=1, c_ms=TRUNK_DIM, a_kcontig=False, stream=stw)
+    if need_denc:
+        ops.gemm(dpre0, store.ptr("Dense_0", "kernel"), ws.ptr(f"denc_{tag}", (B, K)), None, 1, B, K, TRUNK_DIM,
+                 a_ms=TRUNK_DIM, a_ks=1, b_ks=1, b_ns=TRUNK_DIM, c_ms=K, b_ncontig=False, stream=st)
+    ops.colsum(g1, grads.ptr("LayerNorm_1", "bias"), 1, B, Ld, Ld, 0, stw,
                x1=dpre1, out1=grads.ptr("Dense_1", "bias"), x2=g1, mul2=xh1, out2=grads.ptr("LayerNorm_1", "scale"))
     ops.gemm(state_ptr, dpre1, grads.ptr("Dense_1", "kernel"), None, 1, Sd, Ld, B, a_ms=1, a_ks=Sd, b_ks=Ld, b_ns=1,
-             c_ms=Ld, a_kcontig=False, stream=st)
+             c_ms=Ld, a_kcontig=False, stream=stw)
 
 
 # =============================================================================== critic ensemble
@@ -217,7 +254,8 @@ def ensemble_fwd(cfg: NetConfig, tag, store, m0, mstride, E, inp_ptr, ld_inp, B,
     return q
 
 
-def ensemble_bwd(cfg: NetConfig, tag, store, grads, dq_ptr, inp_ptr, ld_inp, B, ws: Workspace, st):
+def ensemble_bwd(cfg: NetConfig, tag, store, grads, dq_ptr, inp_ptr, ld_inp, B, ws: Workspace, st,
+                 gside: "GradSide | None" = None):
     """Backward of the full ensemble from dq (E, B). Writes parameter grads when `grads` is given and
     returns ptr of dinp (B, latent+action) = sum over members."""
     pre = critic_head_prefix(cfg)
@@ -226,9 +264,10 @@ def ensemble_bwd(cfg: NetConfig, tag, store, grads, dq_ptr, inp_ptr, ld_inp, B, 
     nl = len(cfg.hidden_dims)
     hl = dims[-1]
     if grads is not None:
-        ops.colsum(ws.ptr(f"h{nl - 1}_{tag}", (E, B, hl)), grads.ptr(*pre, "Dense_0", "kernel"), E, B, hl, hl, hl, st,
+        stw = gside.fork() if gside is not None else st
+        ops.colsum(ws.ptr(f"h{nl - 1}_{tag}", (E, B, hl)), grads.ptr(*pre, "Dense_0", "kernel"), E, B, hl, hl, hl, stw,
                    w=dq_ptr)
-        ops.colsum(dq_ptr, grads.ptr(*pre, "Dense_0", "bias"), E, B, 1, 1, 1, st)
+        ops.colsum(dq_ptr, grads.ptr(*pre, "Dense_0", "bias"), E, B, 1, 1, 1, stw)
     dy_ptr = None
     for i in range(nl - 1, -1, -1):
         h, hp = dims[i + 1], dims[i]
@@ -246,17 +285,18 @@ def ensemble_bwd(cfg: NetConfig, tag, store, grads, dq_ptr, inp_ptr, ld_inp, B, 
         W = store.ptr(*pre, "MLP_0", f"Dense_{i}", "kernel")
         if grads is not None:
             gb = grads.ptr(*pre, "MLP_0", f"Dense_{i}", "bias")
+            stw = gside.fork() if gside is not None else st       # after this layer's ln_act_bwd
             if ln:
-                ops.colsum(g, grads.ptr(*pre, "MLP_0", f"LayerNorm_{i}", "bias"), E, B, h, h, h, st, x1=dz, out1=gb,
+                ops.colsum(g, grads.ptr(*pre, "MLP_0", f"LayerNorm_{i}", "bias"), E, B, h, h, h, stw, x1=dz, out1=gb,
                            x2=g, mul2=xh, out2=grads.ptr(*pre, "MLP_0", f"LayerNorm_{i}", "scale"))
             else:
-                ops.colsum(dz, gb, E, B, h, h, h, st)
+                ops.colsum(dz, gb, E, B, h, h, h, stw)
             if i == 0:
                 a_ptr, a_zs, a_ks = inp_ptr, 0, ld_inp
             else:
                 a_ptr, a_zs, a_ks = ws.ptr(f"h{i - 1}_{tag}", (E, B, hp)), B * hp, hp
             ops.gemm(a_ptr, dz, grads.ptr(*pre, "MLP_0", f"Dense_{i}", "kernel"), None, E, hp, h, B, a_zs=a_zs, a_ms=1,
-                     a_ks=a_ks, b_zs=B * h, b_ks=h, b_ns=1, c_zs=hp * h, c_ms=h, a_kcontig=False, stream=st)
+                     a_ks=a_ks, b_zs=B * h, b_ks=h, b_ns=1, c_zs=hp * h, c_ms=h, a_kcontig=False, stream=stw)
         if i > 0:
             dy_ptr = ws.ptr(f"edh{i - 1}", (E, B, hp))
             ops.gemm(dz, W, dy_ptr, None, E, B, hp, h, a_zs=B * h, a_ms=h, a_ks=1, b_zs=hp * h, b_ks=1, b_ns=h,
