@@ -136,7 +136,7 @@ class DrQLearner(SACLearner):
         if need_encoder:
             img_bytes = cfg.H * cfg.W * 3 * cfg.stack
             imgs = [feats["aug"][which][cam].data_ptr() + lo * img_bytes for cam in cfg.cams]
-            nn.encoder_bwd(cfg, tag, store, grads, imgs, B, ws, st)
+            nn.encoder_bwd(cfg, tag, store, grads, imgs, B, ws, st, gside=gside)
 
     # ------------------------------------------------------------------ update
     def update(self, batch, utd_ratio: int, pixel_keys=("pixels",)):

@@ -134,20 +134,25 @@ def encoder_fwd(cfg: NetConfig, passes, B, ws: Workspace, st):
                     cfg.enc_dim, B, last.OH * last.OW, last.F, SLE_FEATURES, st, feat_split=split)
 
 
-def encoder_bwd(cfg: NetConfig, tag, store, grads, imgs, B, ws: Workspace, st):
-    """Backward of one encoder pass from ws['denc_<tag>'] (B, enc_dim) into `grads` (same layout as store)."""
+def encoder_bwd(cfg: NetConfig, tag, store, grads, imgs, B, ws: Workspace, st, gside: "GradSide | None" = None):
+    """Backward of one encoder pass from ws['denc_<tag>'] (B, enc_dim) into `grads` (same layout as store).
+    With `gside` the weight-gradient kernels run on its side stream next to the data-gradient chain."""
     layers = cfg.conv_layers()
     nl, ncam = len(layers), len(cfg.cams)
     last = layers[-1]
     split = split_conv_stack(cfg)      # same decision as the forward that filled act* / wd* for this tag
     denc = ws.ptr(f"denc_{tag}", (B, cfg.enc_dim))
     cams = range(ncam)
-    ops.sle_bwd([denc + 4 * ci * last.F * SLE_FEATURES for ci in cams], cfg.enc_dim,
+    sle_args = ([denc + 4 * ci * last.F * SLE_FEATURES for ci in cams], cfg.enc_dim,
                 [store.ptr("image_encoder", f"SpatialLearnedEmbeddings_{ci}", "kernel") for ci in cams],
-                [ws.ptr(f"act{nl - 1}_{tag}_{ci}", (B, last.OH, last.OW, last.F)) for ci in cams],
-                [ws.ptr(f"dact{nl - 1}_{ci}", (B, last.OH, last.OW, last.F)) for ci in cams],
-                [grads.ptr("image_encoder", f"SpatialLearnedEmbeddings_{ci}", "kernel") for ci in cams],
-                B, last.OH * last.OW, last.F, SLE_FEATURES, st, feat_split=split)
+                [ws.ptr(f"act{nl - 1}_{tag}_{ci}", (B, last.OH, last.OW, last.F)) for ci in cams])
+    dfeat = [ws.ptr(f"dact{nl - 1}_{ci}", (B, last.OH, last.OW, last.F)) for ci in cams]
+    dker = [grads.ptr("image_encoder", f"SpatialLearnedEmbeddings_{ci}", "kernel") for ci in cams]
+    if gside is None:
+        ops.sle_bwd(*sle_args, dfeat, dker, B, last.OH * last.OW, last.F, SLE_FEATURES, st, feat_split=split)
+    else:
+        ops.sle_bwd(*sle_args, None, dker, B, last.OH * last.OW, last.F, SLE_FEATURES, gside.fork(), feat_split=split)
+        ops.sle_bwd(*sle_args, dfeat, None, B, last.OH * last.OW, last.F, SLE_FEATURES, st, feat_split=split)
     slab_bytes = max(ops.conv2d_wgrad_workspace_bytes(ncam, B, L.IH, L.IW, L.C, L.K, L.K, L.S, L.F) for L in layers)
     slab = ws.ptr("wgrad_slab", (slab_bytes // 4,))
     for li in range(nl - 1, -1, -1):
@@ -162,7 +167,8 @@ def encoder_bwd(cfg: NetConfig, tag, store, grads, imgs, B, ws: Workspace, st):
             xs, dz,
             [grads.ptr("image_encoder", f"Conv_{ci * nl + li}", "kernel") for ci in range(ncam)],
             [grads.ptr("image_encoder", f"Conv_{ci * nl + li}", "bias") for ci in range(ncam)],
-            slab, slab_bytes, li == 0, B, L.IH, L.IW, L.C, L.K, L.K, L.S, L.F, st)
+            slab, slab_bytes, li == 0, B, L.IH, L.IW, L.C, L.K, L.K, L.S, L.F,
+            gside.fork() if gside is not None else st)      # dz of this layer is ready on the main stream here
         if li > 0:
             P = layers[li - 1]
             dx = [ws.ptr(f"dact{li - 1}_{ci}", (B, P.OH, P.OW, P.F)) for ci in range(ncam)]
