@@ -44,3 +44,35 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libserl_hip.so")
     with pytest.raises(_lib.SerlHipError, match="no CPU fallback"):
         _lib.load()
+
+
+def test_matmul_precision_switch():
+    import serl_amd
+    assert serl_amd.get_matmul_precision() in ("bf16_3x", "highest")
+    serl_amd.set_matmul_precision("highest")
+    assert serl_amd.get_matmul_precision() == "highest"
+    serl_amd.set_matmul_precision("bf16_3x")
+    assert serl_amd.get_matmul_precision() == "bf16_3x"
+    with pytest.raises(ValueError, match="unknown precision"):
+        serl_amd.set_matmul_precision("fp8")
+    from serl_amd import _lib
+    with pytest.raises(ValueError, match="mode must be"):
+        _lib.call("serl_set_matmul_precision", 7)
+
+
+def test_s_format_entry_points_validate_before_touching_the_device():
+    from serl_amd import ops
+    assert ops.convs_weight_bytes(True, 3, 3, 9, 32) == 4 * 96 * 32          # uint8 layer: K padded to KH*32
+    assert ops.convs_weight_bytes(False, 3, 3, 32, 64) == 4 * 288 * 64
+    with pytest.raises(ValueError, match="F % 8"):                           # F % 8
+        ops.convs_fwd([16], [16], [16], [16], False, 1, 8, 8, 8, 3, 3, 2, 5, True, 0)
+    with pytest.raises(ValueError, match="C % 8"):                           # C % 8 for S-format input
+        ops.convs_fwd([16], [16], [16], [16], False, 1, 8, 8, 3, 3, 3, 2, 8, True, 0)
+    with pytest.raises(ValueError, match="16-byte aligned"):
+        ops.convs_fwd([16], [8], [16], [16], False, 1, 8, 8, 8, 3, 3, 2, 8, True, 0)
+    with pytest.raises(ValueError, match="stride"):
+        ops.convs_dgrad([16], [16], [16], [16], 1, 9, 9, 8, 3, 3, 3, 8, 0)
+    with pytest.raises(ValueError, match="workspace too small"):
+        ops.convs_wgrad([16], [16], [16], [16], 16, 4, False, 1, 8, 8, 8, 3, 3, 2, 8, 0)
+    with pytest.raises(ValueError, match="ngroups"):
+        ops.sle_fwd([16] * 9, [16] * 9, [16] * 9, 8, 1, 4, 8, 8, 0)
