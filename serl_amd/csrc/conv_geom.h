@@ -53,12 +53,15 @@ static __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const ReduceAr
   }
 }
 
+#ifndef WGRAD_BLOCKS
+#define WGRAD_BLOCKS 1024
+#endif
 static void wgrad_plan(const ConvGeom& g, int ngroups, int& nsplit, int& klen) {
   const int Kr = g.B * g.OH * g.OW;
   const int kkc1 = g.KH * g.KW * g.C + 1;
   const int bn = g.F <= 32 ? 32 : (g.F <= 64 ? 64 : 128);
   const int tiles = cdiv(kkc1, 128) * cdiv(g.F, bn) * ngroups;
-  int want = cdiv(1024, tiles);
+  int want = cdiv(WGRAD_BLOCKS, tiles);
   if (want < 1) want = 1;
   klen = cdiv(cdiv(Kr, want), 64) * 64;   // multiple of every kernel's K slab
   if (klen < 64) klen = 64;
