@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--phases", action="store_true",
+                    help="after the timed region, one more update() with HIP-event marks between its phases (stderr)")
     ap.add_argument("--precision", default="bf16_3x", choices=["bf16_3x", "highest"],
                     help="serl_amd.set_matmul_precision: bf16_3x (default of the library) or highest (exact fp32 MFMA)")
     args = ap.parse_args()
@@ -143,6 +145,17 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     ops.TIMER = None
+    if args.phases and rank == 0:
+        ops.PHASES = marks = []
+        agent.update(batches[-1], UTD, pixel_keys=KEYS)
+        torch.cuda.synchronize()
+        ops.PHASES = None
+        acc = {}
+        for (n0, e0), (n1, e1) in zip(marks[:-1], marks[1:]):
+            acc.setdefault(f"{n0}->{n1}", []).append(e0.elapsed_time(e1))
+        for k, v in acc.items():
+            print(f"phase {k:28s} n={len(v):3d} mean {sum(v) / len(v) * 1e3:8.1f} us  total {sum(v):7.2f} ms",
+                  file=sys.stderr)
     if dist is not None:
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         import torch.distributed as td

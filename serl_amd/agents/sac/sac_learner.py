@@ -202,6 +202,7 @@ class SACLearner(Agent):
 
         for i in range(utd_ratio):
             lo = i * B
+            ops.phase("step")
             # ---- critic step (sac_learner.py:160-219)
             key_act, rng = prng.split(rng)
             key_sub, rng = prng.split(rng)
@@ -218,6 +219,7 @@ class SACLearner(Agent):
             s0, s1 = ss["s"]
             self._features([("A", actor.store, "next"), ("T", target.store, "next"), ("C", critic.store, "obs")],
                            feats, lo, B, ws, st, save_tag="C", trunk_streams={"T": s0, "C": s1}, fork=ss["fork"])
+            ops.phase("features_fwd")
             nlogp = nn.policy_fwd(cfg, "A", actor.store, zA, ldz, B, ws, st, key_act, rank * B, Bg,
                                   zT + 4 * cfg.latent, ldz, want_logp=self.backup_entropy)
             ss["join"][0].record(s0)
@@ -232,13 +234,16 @@ class SACLearner(Agent):
             ops.td_loss(next_q, emin, rewards.data_ptr() + 4 * lo, masks.data_ptr() + 4 * lo,
                         nlogp if self.backup_entropy else None, log_temp, self.discount, q, E, B, 1.0 / (E * Bg),
                         ws.ptr("target_q", (B,)), dq, info.data_ptr(), st)
+            ops.phase("heads_fwd")
             gside = self._shared.get("grad_side")
             if gside is None:
                 gside = self._shared["grad_side"] = nn.GradSide()
             gside.begin()
             dinp = nn.ensemble_bwd(cfg, "C", critic.store, cgr, dq, zC, ldz, B, ws, st, gside=gside)
+            ops.phase("ensemble_bwd")
             self._features_bwd("C", critic.store, cgr, feats, lo, B, ws, st, dinp, ldz, need_encoder=True, gside=gside)
             gside.join()
+            ops.phase("features_bwd")
             if dist is not None:
                 dist.all_reduce_sum(cgr.flat)
             critic.step += 1
@@ -248,6 +253,7 @@ class SACLearner(Agent):
                             self.tau, 1.0, st)
 
         # ---- actor step on the last minibatch (sac_learner.py:120-144, 235)
+        ops.phase("actor")
         lo = (utd_ratio - 1) * B
         key_pi, rng = prng.split(rng)
         _, rng = prng.split(rng)                           # critic dropout key
@@ -279,6 +285,7 @@ class SACLearner(Agent):
         ops.temperature_update(temp.buf.data_ptr(), info.data_ptr() + 12, 1.0 / Bg, self.target_entropy, temp.lr,
                                ADAM_B1, ADAM_B2, ADAM_EPS, bc1, bc2, info.data_ptr() + 16, st)
 
+        ops.phase("end")
         new_agent = self.replace(actor=actor, critic=critic, target_critic=target, temp=temp, rng=rng)
         h = info.cpu().numpy()                              # one small D2H per update call
         out = {

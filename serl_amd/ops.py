@@ -14,9 +14,21 @@ def current_stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+PHASES = None   # tools/phases.py: list of (name, event) recorded on the current stream at the marks below
+
+
+def phase(name):
+    if PHASES is not None:
+        import torch
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        PHASES.append((name, ev))
+
+
 class KernelTimer:
     """Optional HIP-event bracket around the conv launches (bench.py's live roofline measurement).
-    Events are recorded on torch's current stream, which is the stream the kernels are launched on."""
+    Events are recorded on the stream handle the kernel is launched on (rec), which for the parameter-gradient
+    kernels is a side stream, not torch's current one."""
 
     def __init__(self):
         self.records = {}
@@ -26,6 +38,11 @@ class KernelTimer:
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         self.records.setdefault(key, []).append((a, b, cost))
         return a, b
+
+    @staticmethod
+    def rec(ev, stream):
+        import torch
+        ev.record(torch.cuda.ExternalStream(stream) if stream else torch.cuda.default_stream())
 
     def summary(self):
         """key -> (launches, mean ms, algorithmic flops per launch, algorithmic HBM bytes per launch);
@@ -64,10 +81,10 @@ def conv2d_fwd(xs, ws, bs, ys, in_u8, B, IH, IW, C, KH, KW, stride, F, relu, str
     if TIMER is not None:
         ev = TIMER.bracket(("conv2d_fwd", bool(in_u8), n, B, IH, C, F),
                            conv_cost("fwd", bool(in_u8), n, B, IH, IW, C, KH, KW, stride, F))
-        ev[0].record()
+        TIMER.rec(ev[0], stream)
     call("serl_conv2d_fwd", n, px, pw, pb, py, int(in_u8), B, IH, IW, C, KH, KW, stride, F, int(relu), stream)
     if ev is not None:
-        ev[1].record()
+        TIMER.rec(ev[1], stream)
 
 
 def conv2d_dgrad(dzs, ws, xacts, dxs, B, IH, IW, C, KH, KW, stride, F, stream):
@@ -77,10 +94,10 @@ def conv2d_dgrad(dzs, ws, xacts, dxs, B, IH, IW, C, KH, KW, stride, F, stream):
     if TIMER is not None:
         ev = TIMER.bracket(("conv2d_dgrad", False, n, B, IH, C, F),
                            conv_cost("dgrad", False, n, B, IH, IW, C, KH, KW, stride, F))
-        ev[0].record()
+        TIMER.rec(ev[0], stream)
     call("serl_conv2d_dgrad", n, pz, pw, pa, pd, B, IH, IW, C, KH, KW, stride, F, stream)
     if ev is not None:
-        ev[1].record()
+        TIMER.rec(ev[1], stream)
 
 
 def conv2d_wgrad_workspace_bytes(ngroups, B, IH, IW, C, KH, KW, stride, F) -> int:
@@ -127,10 +144,10 @@ def convs_fwd(xs, wfs, bs, ys, in_u8, B, IH, IW, C, KH, KW, stride, F, relu, str
     if TIMER is not None:
         ev = TIMER.bracket(("convs_fwd", bool(in_u8), n, B, IH, C, F),
                            conv_cost("fwd", bool(in_u8), n, B, IH, IW, C, KH, KW, stride, F))
-        ev[0].record()
+        TIMER.rec(ev[0], stream)
     call("serl_convs_fwd", n, px, pw, pb, py, int(in_u8), B, IH, IW, C, KH, KW, stride, F, int(relu), stream)
     if ev is not None:
-        ev[1].record()
+        TIMER.rec(ev[1], stream)
 
 
 def convs_dgrad(dzs, wds, xacts, dxs, B, IH, IW, C, KH, KW, stride, F, stream):
@@ -140,10 +157,10 @@ def convs_dgrad(dzs, wds, xacts, dxs, B, IH, IW, C, KH, KW, stride, F, stream):
     if TIMER is not None:
         ev = TIMER.bracket(("convs_dgrad", False, n, B, IH, C, F),
                            conv_cost("dgrad", False, n, B, IH, IW, C, KH, KW, stride, F))
-        ev[0].record()
+        TIMER.rec(ev[0], stream)
     call("serl_convs_dgrad", n, pz, pw, pa, pd, B, IH, IW, C, KH, KW, stride, F, stream)
     if ev is not None:
-        ev[1].record()
+        TIMER.rec(ev[1], stream)
 
 
 def convs_wgrad(xs, dzs, dws, dbs, workspace, workspace_bytes, in_u8, B, IH, IW, C, KH, KW, stride, F, stream):
@@ -153,11 +170,11 @@ def convs_wgrad(xs, dzs, dws, dbs, workspace, workspace_bytes, in_u8, B, IH, IW,
     if TIMER is not None:
         ev = TIMER.bracket(("convs_wgrad", bool(in_u8), n, B, IH, C, F),
                            conv_cost("wgrad", bool(in_u8), n, B, IH, IW, C, KH, KW, stride, F))
-        ev[0].record()
+        TIMER.rec(ev[0], stream)
     call("serl_convs_wgrad", n, px, pz, pw, pb, workspace, workspace_bytes, int(in_u8), B, IH, IW, C, KH, KW,
          stride, F, stream)
     if ev is not None:
-        ev[1].record()
+        TIMER.rec(ev[1], stream)
 
 
 def gemm(a, b, c, bias, nbatch, M, N, K, *, a_zs=0, a_ms, a_ks, b_zs=0, b_ks, b_ns, c_zs=0, c_ms,
