@@ -57,9 +57,15 @@ int serl_merge_split(const void* in, float* out, long long rows, int cols, void*
 int serl_convs_prep_weights(int ngroups, const float* const* w, void* const* wf, void* const* wd, int in_u8, int KH,
                             int KW, int C, int F, void* stream);
 int serl_convs_fwd(int ngroups, const void* const* x, const void* const* wf, const float* const* bias, void* const* y,
-                   int in_u8, int B, int IH, int IW, int C, int KH, int KW, int stride, int F, int relu, void* stream);
+                   int in_u8, int B, int IH, int IW, int C, int KH, int KW, int stride, int F, int relu,
+                   void* const* rmask, void* stream);
+/* rmask (may be NULL, entries may be NULL): per group a byte mask [B*OH*OW][F/8] of y, bit j of byte [pixel][n/8] =
+ * "y[pixel][n+j] != 0" -- the ReLU mask for the data gradient of the next layer, 32x smaller than y's hi plane.
+ * serl_convs_dgrad masks dx with xact: the layer's post-ReLU input in S format (xact_bits = 0), or that byte mask
+ * (xact_bits = 1); xact NULL or a NULL entry: no mask. */
 int serl_convs_dgrad(int ngroups, const void* const* dz, const void* const* wd, const void* const* xact,
-                     void* const* dx, int B, int IH, int IW, int C, int KH, int KW, int stride, int F, void* stream);
+                     void* const* dx, int B, int IH, int IW, int C, int KH, int KW, int stride, int F, int xact_bits,
+                     void* stream);
 int serl_convs_wgrad(int ngroups, const void* const* x, const void* const* dz, float* const* dw, float* const* dbias,
                      float* workspace, long long workspace_bytes, int in_u8, int B, int IH, int IW, int C, int KH,
                      int KW, int stride, int F, void* stream);

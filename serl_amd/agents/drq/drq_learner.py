@@ -115,7 +115,7 @@ class DrQLearner(SACLearner):
         for tag, store, which in passes:
             imgs = [feats["aug"][which][cam].data_ptr() + lo * img_bytes for cam in cfg.cams]
             enc_passes.append((tag, store, imgs))
-        nn.encoder_fwd(cfg, enc_passes, B, ws, st)
+        nn.encoder_fwd(cfg, enc_passes, B, ws, st, mask_tag=save_tag)
         if fork is not None:          # the trunks of the passes are independent: side streams wait for the encoders
             fork.record(torch.cuda.current_stream())
             for s_ in trunk_streams.values():
@@ -136,7 +136,7 @@ class DrQLearner(SACLearner):
         if need_encoder:
             img_bytes = cfg.H * cfg.W * 3 * cfg.stack
             imgs = [feats["aug"][which][cam].data_ptr() + lo * img_bytes for cam in cfg.cams]
-            nn.encoder_bwd(cfg, tag, store, grads, imgs, B, ws, st, gside=gside)
+            nn.encoder_bwd(cfg, tag, store, grads, imgs, B, ws, st, gside=gside, use_masks=True)
 
     # ------------------------------------------------------------------ update
     def update(self, batch, utd_ratio: int, pixel_keys=("pixels",)):

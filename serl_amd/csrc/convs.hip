@@ -24,7 +24,7 @@ __device__ __forceinline__ void split1(float v, ushort_t& hi, ushort_t& lo) {
 // B: KC, rows = output channels, from wf = S-format [F][2][Kp] (k order as A)
 template <bool U8>
 struct ConvFwdS {
-  static constexpr bool A_KC = true, B_KC = true, A_LO = !U8, B_LO = true, A_U8 = U8, S_OUT = true, XCD_SWZ = false;
+  static constexpr bool A_KC = true, B_KC = true, A_LO = !U8, B_LO = true, A_U8 = U8, S_OUT = true, XCD_SWZ = false, MASK_OUT = true;
   ConvGeom g;
   int Kp;
   float scale;                      // 1/255 for uint8 input, else 1
@@ -33,15 +33,21 @@ struct ConvFwdS {
   const ushort_t* wf[MAXG];
   const float* bias[MAXG];
   ushort_t* y[MAXG];
+  unsigned char* rmask[MAXG];       // optional byte mask of y's non-zero elements (nullptr: none), see sgemm.h MASK_OUT
   int relu;
-  struct Ctx { const char* x; const ushort_t* wf; const float* bias; ushort_t* y; };
+  struct Ctx { const char* x; const ushort_t* wf; const float* bias; ushort_t* y; unsigned char* rmask; };
   struct ARow { uint32_t base; bool ok; };
   struct AK { uint32_t off; int sh; bool ok; };
   struct BRow { uint32_t base; bool ok; };
   struct BK_ { uint32_t off; bool ok; };
-  struct ORow { uint32_t base; };
+  struct ORow { uint32_t base, pix; };
   struct OCol { float bias; };
-  __device__ bool init(Ctx& c, int z) const { c.x = (const char*)x[z]; c.wf = wf[z]; c.bias = bias[z]; c.y = y[z]; return true; }
+  __device__ bool init(Ctx& c, int z) const {
+    c.x = (const char*)x[z]; c.wf = wf[z]; c.bias = bias[z]; c.y = y[z]; c.rmask = rmask[z];
+    return true;
+  }
+  __device__ unsigned char* s_mask(const Ctx& c) const { return c.rmask; }
+  __device__ uint32_t s_pix(const ORow& o) const { return o.pix; }
   __device__ int M(const Ctx&) const { return g.B * g.OH * g.OW; }
   __device__ int N(const Ctx&) const { return g.F; }
   __device__ int K(const Ctx&) const { return Kp; }
@@ -104,7 +110,7 @@ struct ConvFwdS {
   __device__ ushort_t* s_out(const Ctx& c) const { return c.y; }
   __device__ size_t s_base(const ORow& o) const { return o.base; }
   __device__ void o_col(const Ctx& c, int n, OCol& o) const { o.bias = c.bias[n]; }
-  __device__ void o_row(const Ctx&, int m, ORow& o) const { o.base = (uint32_t)m * 2 * g.F; }
+  __device__ void o_row(const Ctx&, int m, ORow& o) const { o.base = (uint32_t)m * 2 * g.F; o.pix = (uint32_t)m; }
   __device__ float o_aux(const Ctx&, const ORow&, int, int) const { return 0.f; }
   __device__ void store(const Ctx& c, const ORow& o, const OCol& oc, int n, int, float v, float) const {
     v = fmaf(v, scale, oc.bias);
@@ -120,12 +126,13 @@ struct ConvFwdS {
 // per parity class of input pixels (conv.hip): A: KC, rows = input pixels of the class, k = (tap, f) from dz (S);
 // B: KC, rows = input channels, from wd = S-format of the HWIO kernel viewed as [(ky,kx,c)][2][F].
 struct ConvDgradS {
-  static constexpr bool A_KC = true, B_KC = true, A_LO = true, B_LO = true, A_U8 = false, S_OUT = true, XCD_SWZ = false;
+  static constexpr bool A_KC = true, B_KC = true, A_LO = true, B_LO = true, A_U8 = false, S_OUT = true, XCD_SWZ = false, MASK_OUT = false;
   ConvGeom g;
   int G;
   const ushort_t* dz[MAXG];
   const ushort_t* wd[MAXG];
-  const ushort_t* xact[MAXG];
+  const ushort_t* xact[MAXG];       // post-ReLU input of the layer (S format; its hi plane is the mask), or with
+  int xact_bits;                    // xact_bits: the byte mask written by the forward (ConvFwdS::rmask)
   ushort_t* dx[MAXG];
   struct Cls { int py, px, IHc, IWc, TY, TX; FastDiv d_hw, d_w, d_tx; };
   Cls cls[4];
@@ -139,7 +146,7 @@ struct ConvDgradS {
   struct AK { int dpix, jy, jx, f0; bool ok; };
   struct BRow { uint32_t c; bool ok; };
   struct BK_ { uint32_t off; bool ok; };
-  struct ORow { uint32_t base; };
+  struct ORow { uint32_t base, pix; };
   struct OCol {};
   __device__ bool init(Ctx& c, int z) const {
     const int ci = z / G, gi = z - ci * G;
@@ -193,12 +200,20 @@ struct ConvDgradS {
   __device__ void o_row(const Ctx& c, int m, ORow& o) const {
     const uint32_t b = fd_div((uint32_t)m, c.d_hw), rem = m - b * (c.IHc * c.IWc);
     const uint32_t iyp = fd_div(rem, c.d_w), ixp = rem - iyp * c.IWc;
-    o.base = ((b * g.IH + iyp * g.S + c.py) * g.IW + ixp * g.S + c.px) * 2 * g.C;
+    o.pix = (b * g.IH + iyp * g.S + c.py) * g.IW + ixp * g.S + c.px;
+    o.base = o.pix * 2 * g.C;
   }
   struct SCol {};
   __device__ void s_col(const Ctx&, int, SCol&) const {}
   __device__ void s_finish(const Ctx& c, const ORow& o, const SCol&, int n, float (&v)[8]) const {
     if (c.xact == nullptr) return;
+    if (xact_bits) {
+      const uint32_t bits = reinterpret_cast<const unsigned char*>(c.xact)[(size_t)o.pix * (g.C >> 3) + (n >> 3)];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (!(bits & (1u << j))) v[j] = 0.f;
+      return;
+    }
     const u32x4_t m = *reinterpret_cast<const u32x4_t*>(c.xact + o.base + n);     // hi plane of the post-ReLU input
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -446,7 +461,7 @@ extern "C" int serl_convs_prep_weights(int ngroups, const float* const* w, void*
 
 extern "C" int serl_convs_fwd(int ngroups, const void* const* x, const void* const* wf, const float* const* bias,
                               void* const* y, int in_u8, int B, int IH, int IW, int C, int KH, int KW, int stride, int F,
-                              int relu, void* stream) {
+                              int relu, void* const* rmask, void* stream) {
   SERL_CHECK_ARG(ngroups >= 1 && ngroups <= MAXG, "convs_fwd: ngroups must be in [1,%d]", MAXG);
   ConvGeom g;
   if (int e = make_geom(g, B, IH, IW, C, KH, KW, stride, F)) return e;
@@ -458,7 +473,10 @@ extern "C" int serl_convs_fwd(int ngroups, const void* const* x, const void* con
 #define FILL(p)                                                                                              \
   p.g = g; p.relu = relu; p.Kp = s_kp(in_u8, KH, KW, C); p.scale = in_u8 ? 1.0f / 255.0f : 1.0f;             \
   p.d_c = make_fastdiv(C); p.d_kw = make_fastdiv(KW);                                                        \
-  for (int i = 0; i < ngroups; ++i) { p.x[i] = x[i]; p.wf[i] = (const ushort_t*)wf[i]; p.bias[i] = bias[i]; p.y[i] = (ushort_t*)y[i]; }
+  for (int i = 0; i < ngroups; ++i) {                                                                        \
+    p.x[i] = x[i]; p.wf[i] = (const ushort_t*)wf[i]; p.bias[i] = bias[i]; p.y[i] = (ushort_t*)y[i];          \
+    p.rmask[i] = rmask ? (unsigned char*)rmask[i] : nullptr;                                                 \
+  }
   if (in_u8) { ConvFwdS<true> p; FILL(p) return s_launch_by_n(S_FWD, p, M, F, 1, ngroups, st, "convs_fwd_u8"); }
   ConvFwdS<false> p; FILL(p) return s_launch_by_n(S_FWD, p, M, F, 1, ngroups, st, "convs_fwd");
 #undef FILL
@@ -466,7 +484,7 @@ extern "C" int serl_convs_fwd(int ngroups, const void* const* x, const void* con
 
 extern "C" int serl_convs_dgrad(int ngroups, const void* const* dz, const void* const* wd, const void* const* xact,
                                 void* const* dx, int B, int IH, int IW, int C, int KH, int KW, int stride, int F,
-                                void* stream) {
+                                int xact_bits, void* stream) {
   SERL_CHECK_ARG(ngroups >= 1 && ngroups <= MAXG, "convs_dgrad: ngroups must be in [1,%d]", MAXG);
   ConvGeom g;
   if (int e = make_geom(g, B, IH, IW, C, KH, KW, stride, F)) return e;
@@ -474,7 +492,7 @@ extern "C" int serl_convs_dgrad(int ngroups, const void* const* dz, const void* 
   SERL_CHECK_ARG(F % 8 == 0 && C % 8 == 0, "convs_dgrad: need C %% 8 == 0 and F %% 8 == 0");
   SERL_CHECK_ARG(all_aligned16(dz, ngroups) && all_aligned16(wd, ngroups) && all_aligned16(dx, ngroups),
                  "convs_dgrad: S-format tensors must be 16-byte aligned");
-  ConvDgradS p; p.g = g; p.G = ngroups;
+  ConvDgradS p; p.g = g; p.G = ngroups; p.xact_bits = xact_bits;
   p.d_f_ = make_fastdiv(g.F);
   for (int ci = 0; ci < stride * stride; ++ci) {
     ConvDgradS::Cls& k = p.cls[ci];

@@ -49,7 +49,8 @@ constexpr int s_rc_stride(int rows) { return ((2 * rows - 64 + 127) / 128) * 128
 //   (zero page when out of range); same for b_*;  epilogue members as in igemm.h, or with S_OUT = true:
 //   SCol + s_col(ctx, n, SCol&) (per 8-column context, e.g. bias), s_finish(ctx, ORow, SCol, n, float v[8]) (bias /
 //   activation / mask on 8 consecutive columns), s_out(ctx) (ushort* of the S-format output), s_base(ORow) (ushort
-//   offset of the row's record: hi plane at base + n, lo plane at base + N + n).
+//   offset of the row's record: hi plane at base + n, lo plane at base + N + n); MASK_OUT = true adds s_mask(ctx)
+//   (byte mask output or nullptr: byte [s_pix(ORow)][n / 8], bit j = element n + j has a non-zero hi plane).
 template <class P, class T, int LBUF>
 constexpr int sgemm_lds_bytes() {
   constexpr int KC_STRIDE = (T::BK + 8) * 2;
@@ -368,6 +369,19 @@ __global__ __launch_bounds__(T::NT, SG_MIN_WAVES) void sgemm_kernel(const P p) {
         unsigned short* dst = out + p.s_base(orow) + n;
         *reinterpret_cast<u32x4_t*>(dst) = hi;
         *reinterpret_cast<u32x4_t*>(dst + N) = lo;
+        if constexpr (P::MASK_OUT) {
+          // 1 bit per element "hi plane != 0" (the ReLU mask the data gradient of the next layer needs): a byte per
+          // 8 channels instead of a 16-byte read of the hi plane (a full 128-byte line per pixel when C = 32)
+          if (unsigned char* mk = p.s_mask(ctx)) {
+            uint32_t bits = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              bits |= (hi[j] & 0x7fffu) ? (1u << (2 * j)) : 0u;
+              bits |= (hi[j] & 0x7fff0000u) ? (2u << (2 * j)) : 0u;
+            }
+            mk[(size_t)p.s_pix(orow) * (N >> 3) + (n >> 3)] = (unsigned char)bits;
+          }
+        }
       }
     }
   } else {

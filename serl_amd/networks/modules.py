@@ -102,9 +102,15 @@ def split_conv_stack(cfg: NetConfig) -> bool:
     return True
 
 
-def encoder_fwd(cfg: NetConfig, passes, B, ws: Workspace, st):
+def _rmask_ptr(ws, li, tag, ci, B, L):
+    return ws.ptr(f"rmask{li}_{tag}_{ci}", ((B * L.OH * L.OW * L.F // 8 + 3) // 4,))
+
+
+def encoder_fwd(cfg: NetConfig, passes, B, ws: Workspace, st, mask_tag=None):
     """passes: list of (tag, ParamStore, [u8 image ptr per camera in cfg.cams order]).
-    All passes x cameras run as groups of one launch per conv layer. Writes ws['enc_<tag>'] (B, enc_dim)."""
+    All passes x cameras run as groups of one launch per conv layer. Writes ws['enc_<tag>'] (B, enc_dim).
+    S-format stack: the pass `mask_tag` (the one encoder_bwd will be called for) also writes the ReLU byte masks of
+    its hidden activations, which encoder_bwd(use_masks=True) reads instead of the activations' hi planes."""
     layers = cfg.conv_layers()
     nl, ncam = len(layers), len(cfg.cams)
     split = split_conv_stack(cfg)
@@ -121,7 +127,10 @@ def encoder_fwd(cfg: NetConfig, passes, B, ws: Workspace, st):
                 wfs = [ws.ptr(f"wf{li}_{g[0]}_{g[2]}", (nwf,)) for g in chunk]
                 wds = [ws.ptr(f"wd{li}_{g[0]}_{g[2]}", (L.K * L.K * L.C * L.F,)) for g in chunk] if li > 0 else None
                 ops.convs_prep_weights(wsp, wfs, wds, li == 0, L.K, L.K, L.C, L.F, st)
-                ops.convs_fwd(xs, wfs, bsp, ys, li == 0, B, L.IH, L.IW, L.C, L.K, L.K, L.S, L.F, True, st)
+                rm = None
+                if mask_tag is not None and li < nl - 1 and any(g[0] == mask_tag for g in chunk):
+                    rm = [_rmask_ptr(ws, li, g[0], g[2], B, L) if g[0] == mask_tag else 0 for g in chunk]
+                ops.convs_fwd(xs, wfs, bsp, ys, li == 0, B, L.IH, L.IW, L.C, L.K, L.K, L.S, L.F, True, st, rmasks=rm)
             else:
                 ops.conv2d_fwd(xs, wsp, bsp, ys, li == 0, B, L.IH, L.IW, L.C, L.K, L.K, L.S, L.F, True, st)
             xs = ys
@@ -134,9 +143,11 @@ def encoder_fwd(cfg: NetConfig, passes, B, ws: Workspace, st):
                     cfg.enc_dim, B, last.OH * last.OW, last.F, SLE_FEATURES, st, feat_split=split)
 
 
-def encoder_bwd(cfg: NetConfig, tag, store, grads, imgs, B, ws: Workspace, st, gside: "GradSide | None" = None):
+def encoder_bwd(cfg: NetConfig, tag, store, grads, imgs, B, ws: Workspace, st, gside: "GradSide | None" = None,
+                use_masks=False):
     """Backward of one encoder pass from ws['denc_<tag>'] (B, enc_dim) into `grads` (same layout as store).
-    With `gside` the weight-gradient kernels run on its side stream next to the data-gradient chain."""
+    With `gside` the weight-gradient kernels run on its side stream next to the data-gradient chain.
+    use_masks: the forward of this pass ran with mask_tag=tag (S-format stack only)."""
     layers = cfg.conv_layers()
     nl, ncam = len(layers), len(cfg.cams)
     last = layers[-1]
@@ -174,7 +185,11 @@ def encoder_bwd(cfg: NetConfig, tag, store, grads, imgs, B, ws: Workspace, st, g
             dx = [ws.ptr(f"dact{li - 1}_{ci}", (B, P.OH, P.OW, P.F)) for ci in range(ncam)]
             if split:
                 wds = [ws.ptr(f"wd{li}_{tag}_{ci}", (L.K * L.K * L.C * L.F,)) for ci in range(ncam)]
-                ops.convs_dgrad(dz, wds, xs, dx, B, L.IH, L.IW, L.C, L.K, L.K, L.S, L.F, st)
+                if use_masks:
+                    rm = [_rmask_ptr(ws, li - 1, tag, ci, B, P) for ci in range(ncam)]
+                    ops.convs_dgrad(dz, wds, rm, dx, B, L.IH, L.IW, L.C, L.K, L.K, L.S, L.F, st, xact_bits=True)
+                else:
+                    ops.convs_dgrad(dz, wds, xs, dx, B, L.IH, L.IW, L.C, L.K, L.K, L.S, L.F, st)
             else:
                 ops.conv2d_dgrad(dz, [store.ptr("image_encoder", f"Conv_{ci * nl + li}", "kernel") for ci in range(ncam)],
                                  xs, dx, B, L.IH, L.IW, L.C, L.K, L.K, L.S, L.F, st)

@@ -137,7 +137,7 @@ def convs_prep_weights(ws, wfs, wds, in_u8, KH, KW, C, F, stream):
     call("serl_convs_prep_weights", n, pw, pf, pd, int(in_u8), KH, KW, C, F, stream)
 
 
-def convs_fwd(xs, wfs, bs, ys, in_u8, B, IH, IW, C, KH, KW, stride, F, relu, stream):
+def convs_fwd(xs, wfs, bs, ys, in_u8, B, IH, IW, C, KH, KW, stride, F, relu, stream, rmasks=None):
     n = len(xs)
     px, kx = ptr_table(xs); pw, kw = ptr_table(wfs); pb, kb = ptr_table(bs); py, ky = ptr_table(ys)
     ev = None
@@ -145,12 +145,13 @@ def convs_fwd(xs, wfs, bs, ys, in_u8, B, IH, IW, C, KH, KW, stride, F, relu, str
         ev = TIMER.bracket(("convs_fwd", bool(in_u8), n, B, IH, C, F),
                            conv_cost("fwd", bool(in_u8), n, B, IH, IW, C, KH, KW, stride, F))
         TIMER.rec(ev[0], stream)
-    call("serl_convs_fwd", n, px, pw, pb, py, int(in_u8), B, IH, IW, C, KH, KW, stride, F, int(relu), stream)
+    pm, km = ptr_table(rmasks) if rmasks is not None else (None, None)
+    call("serl_convs_fwd", n, px, pw, pb, py, int(in_u8), B, IH, IW, C, KH, KW, stride, F, int(relu), pm, stream)
     if ev is not None:
         TIMER.rec(ev[1], stream)
 
 
-def convs_dgrad(dzs, wds, xacts, dxs, B, IH, IW, C, KH, KW, stride, F, stream):
+def convs_dgrad(dzs, wds, xacts, dxs, B, IH, IW, C, KH, KW, stride, F, stream, xact_bits=False):
     n = len(dzs)
     pz, kz = ptr_table(dzs); pw, kw = ptr_table(wds); pa, ka = ptr_table(xacts); pd, kd = ptr_table(dxs)
     ev = None
@@ -158,7 +159,7 @@ def convs_dgrad(dzs, wds, xacts, dxs, B, IH, IW, C, KH, KW, stride, F, stream):
         ev = TIMER.bracket(("convs_dgrad", False, n, B, IH, C, F),
                            conv_cost("dgrad", False, n, B, IH, IW, C, KH, KW, stride, F))
         TIMER.rec(ev[0], stream)
-    call("serl_convs_dgrad", n, pz, pw, pa, pd, B, IH, IW, C, KH, KW, stride, F, stream)
+    call("serl_convs_dgrad", n, pz, pw, pa, pd, B, IH, IW, C, KH, KW, stride, F, int(xact_bits), stream)
     if ev is not None:
         TIMER.rec(ev[1], stream)
 

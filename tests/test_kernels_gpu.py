@@ -173,9 +173,13 @@ def test_convs_fwd_dgrad_wgrad(dev, case):
         refs.append((xf, w, b))
     ops.convs_prep_weights([t.data_ptr() for t in keep], [t.data_ptr() for t in wfs], [t.data_ptr() for t in wds],
                            u8, K, K, Cin, F, st)
+    rmask0 = torch.full((B * OH * OW * F // 8,), 0xAA, dtype=torch.uint8, device=dev)   # group 0 only
     ops.convs_fwd([t.data_ptr() for t in xs], [t.data_ptr() for t in wfs], [t.data_ptr() for t in bs],
-                  [t.data_ptr() for t in ys], u8, B, IH, IW, Cin, K, K, S, F, True, st)
+                  [t.data_ptr() for t in ys], u8, B, IH, IW, Cin, K, K, S, F, True, st,
+                  rmasks=[rmask0.data_ptr(), 0])
     torch.cuda.synchronize()
+    y0 = _from_s(ops, ys[0], B * OH * OW, F, st).reshape(-1, F)
+    np.testing.assert_array_equal(rmask0.cpu().numpy(), np.packbits(y0 != 0, axis=1, bitorder="little").reshape(-1))
     dzs, dzf, dxs, dws, dbs = [], [], [], [], []
     for g in range(G):
         xf, w, b = refs[g]
@@ -196,6 +200,15 @@ def test_convs_fwd_dgrad_wgrad(dev, case):
     if not u8:
         ops.convs_dgrad([t.data_ptr() for t in dzs], [t.data_ptr() for t in wds], [t.data_ptr() for t in xs],
                         [t.data_ptr() for t in dxs], B, IH, IW, Cin, K, K, S, F, st)
+        # the same data gradient masked by the byte mask of x instead of x's hi plane: bit-identical
+        xm = [dv(np.packbits(refs[g][0].reshape(-1, Cin) != 0, axis=1, bitorder="little").reshape(-1), dev)
+              for g in range(G)]
+        dxb = [torch.full_like(t, -1) for t in dxs]
+        ops.convs_dgrad([t.data_ptr() for t in dzs], [t.data_ptr() for t in wds], [t.data_ptr() for t in xm],
+                        [t.data_ptr() for t in dxb], B, IH, IW, Cin, K, K, S, F, st, xact_bits=True)
+        torch.cuda.synchronize()
+        for g in range(G):
+            assert torch.equal(dxb[g], dxs[g]), f"byte-mask dgrad differs from hi-plane-mask dgrad, group {g}"
     torch.cuda.synchronize()
     for g in range(G):
         xf, w, b = refs[g]

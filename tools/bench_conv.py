@@ -60,7 +60,11 @@ for li, (IH, C, F) in enumerate(LAYERS):
             ops.convs_prep_weights(p(ws), p(wf), p(wd), u8, 3, 3, C, F, st)
             yS = [torch.empty(B * OH * OH * F * 2, dtype=torch.int16, device=dev) for _ in range(G)]
             if what == "fwd":
-                fn = lambda: ops.convs_fwd(p(xS), p(wf), p(bs), p(yS), u8, B, IH, IH, C, 3, 3, 2, F, True, st)
+                rm = None
+                if os.environ.get("BENCH_RMASK"):     # 2 of the 6 groups (the critic pass) write ReLU byte masks
+                    rmt = [torch.empty(B * OH * OH * F // 8, dtype=torch.uint8, device=dev) for _ in range(2)]
+                    rm = p(rmt) + [0] * (G - 2)
+                fn = lambda: ops.convs_fwd(p(xS), p(wf), p(bs), p(yS), u8, B, IH, IH, C, 3, 3, 2, F, True, st, rmasks=rm)
             elif what == "wgrad":
                 nb = ops.conv2d_wgrad_workspace_bytes(G, B, IH, IH, C, 3, 3, 2, F)
                 wk = torch.empty(nb // 4, device=dev)
@@ -69,7 +73,11 @@ for li, (IH, C, F) in enumerate(LAYERS):
                                              2, F, st)
             else:
                 dxS = [torch.empty(B * IH * IH * C * 2, dtype=torch.int16, device=dev) for _ in range(G)]
-                fn = lambda: ops.convs_dgrad(p(dzS), p(wd), p(xS), p(dxS), B, IH, IH, C, 3, 3, 2, F, st)
+                if os.environ.get("BENCH_BITMASK"):
+                    bm = [torch.randint(0, 256, (B * IH * IH * C // 8,), dtype=torch.uint8, device="cuda") for _ in range(G)]
+                    fn = lambda: ops.convs_dgrad(p(dzS), p(wd), p(bm), p(dxS), B, IH, IH, C, 3, 3, 2, F, st, xact_bits=True)
+                else:
+                    fn = lambda: ops.convs_dgrad(p(dzS), p(wd), [0] * G if os.environ.get("BENCH_NOMASK") else p(xS), p(dxS), B, IH, IH, C, 3, 3, 2, F, st)
         elif what == "fwd":
             fn = lambda: ops.conv2d_fwd(p(xs), p(ws), p(bs), p(ys), li == 0, B, IH, IH, C, 3, 3, 2, F, True, st)
         elif what == "wgrad":
