@@ -188,3 +188,69 @@ def test_device_replay_feeds_update(dev):
     a2, i2 = agent.update(hostb, 2, pixel_keys=keys)
     assert i1 == i2
     assert torch.equal(a1.critic.store.flat, a2.critic.store.flat)
+
+
+def test_full_size_update_properties(dev):
+    """BASELINE config 3 with the RLPD settings at FULL size (2 x 128^2 cameras, stack 3, batch 256, 10/2 critics,
+    UTD 20: 5120 rows per call), where the CPU oracle would take minutes -- size-independent properties instead:
+      1. the augmented uint8 images of a strided sample of the 5120 rows are bit-exact against the oracle's crop of
+         the host buffer's windows (index stream, frame-stack gather, _unpack, per-row threefry offsets, edge clamp);
+      2. the same update() run twice from the same agent and batch is bit-identical in every parameter, optimizer
+         moment and logged scalar (the parameter-gradient kernels run on side streams; split-K slabs are reduced in
+         a fixed order -- a race or an atomic accumulation would show here);
+      3. the rng chain advances exactly as the oracle's split sequence; all outputs are finite."""
+    from oracle import learner as ol
+    from oracle import prng as oprng
+    from serl_amd.agents import DrQLearner
+    from serl_amd.data import MemoryEfficientReplayBuffer
+    from helpers import rollout_transitions
+    keys = ("wrist_1", "wrist_2")
+    H = W = 128; S = 3; B, U = 256, 20
+    n = B * U
+    obs_space, act_space = pixel_spaces(keys, H, W, S, 19, 7)
+    bufs = [MemoryEfficientReplayBuffer(obs_space, act_space, 1500, pixel_keys=keys, device=d) for d in (None, "cuda")]
+    rng = np.random.default_rng(5)
+    for tr in rollout_transitions(rng, 1200, keys, H, W, S, 19, 7, episode_len=100):
+        for b in bufs:
+            b.insert(tr)
+    args = dict(batch_size=n, pack_obs_and_next_obs=True, demo_batch_size=n // 2, demo_size=300)
+    for b in bufs:
+        b.seed(3)
+    lazy = next(bufs[1].get_iterator(queue_size=1, sample_args=args))
+    host = bufs[0].sample(**args)
+    agent = DrQLearner.create(7, obs_space, act_space, pixel_keys=keys, cnn_features=(32, 64, 128, 256),
+                              cnn_filters=(3, 3, 3, 3), cnn_strides=(2, 2, 2, 2), latent_dim=64, num_qs=10,
+                              num_min_qs=2, critic_layer_norm=True, backup_entropy=False, init_temperature=0.1)
+    a1, i1 = agent.update(lazy, U, pixel_keys=keys)
+    # 1. augmentation, every 37th row
+    rows = np.arange(0, n, 37)
+    ws = a1._ws(B)
+    r, key = oprng.split(agent.rng)
+    for side, sl in (("obs", slice(0, S)), ("next", slice(1, S + 1))):
+        kk = key
+        for cam in keys:
+            kcam, kk = oprng.split(kk)
+            offs = ol.crop_offsets_fast(kcam, n)[rows]
+            want = ol.random_crop_batch(host["observations"][cam][rows][..., sl], offs)
+            got = ws.tensor(f"aug_{side}_{cam}", (n, H, W, 3 * S), torch.uint8)[torch.as_tensor(rows, device=dev)]
+            assert np.array_equal(got.cpu().numpy().reshape(len(rows), H, W, 3, S), want), f"aug {side} {cam}"
+        r, key = oprng.split(r)
+    # 2. bit-identical repeat
+    a2, i2 = agent.update(lazy, U, pixel_keys=keys)
+    assert i1 == i2, (i1, i2)
+    for name in ("actor", "critic", "target_critic"):
+        t1, t2 = getattr(a1, name), getattr(a2, name)
+        assert torch.equal(t1.store.flat, t2.store.flat), f"{name} parameters differ between two identical calls"
+        if name != "target_critic":
+            assert torch.equal(t1.mu, t2.mu) and torch.equal(t1.nu, t2.nu), f"{name} Adam moments differ"
+    assert torch.equal(a1.temp.buf, a2.temp.buf)
+    # 3. rng chain: drq_learner.py:174-177 (two splits), sac_learner.py:166-209 (4 per critic step), :121-122 (2)
+    e = agent.rng
+    e, _ = oprng.split(e)
+    e, _ = oprng.split(e)
+    for _ in range(4 * U + 2):
+        _, e = oprng.split(e)
+    assert np.array_equal(a1.rng, e)
+    assert all(np.isfinite(v) for v in i1.values())
+    assert bool(torch.isfinite(a1.critic.store.flat).all()) and bool(torch.isfinite(a1.actor.store.flat).all())
+    assert int(a1.critic.step) == int(agent.critic.step) + U and int(a1.actor.step) == int(agent.actor.step) + 1
