@@ -27,3 +27,31 @@ def _share_encoder(source, target):
 
 
 __all__ = ["_unpack", "_share_encoder"]
+
+
+def get_data(data, start, end):
+    """serl/utils/commons.py:49-61: slice every leaf of a (nested) dataset dict."""
+    if type(data) == dict:                                   # noqa: E721  (the reference tests the exact type)
+        return {k: get_data(v, start, end) for k, v in data.items()}
+    return data[start:end]
+
+
+def _reset_weights(source, target):
+    """serl/utils/commons.py:76-90: copy every top-level subtree WITHOUT 'encoder' in its name from source to target."""
+    replacers = {k: v for k, v in source.params.items() if "encoder" not in k}
+    return target.replace(params=target.params.copy(add_or_replace=replacers))
+
+
+def ema(series, alpha=0.5):
+    """serl/utils/commons.py:92-104."""
+    import numpy as np
+    smoothed = np.zeros_like(series, dtype=float)
+    smoothed[0] = series[0]
+    for i in range(1, len(series)):
+        smoothed[i] = alpha * series[i] + (1 - alpha) * smoothed[i - 1]
+    return smoothed
+
+
+from .checkpoints import restore_checkpoint, restore_checkpoint_, save_checkpoint  # noqa: E402
+
+__all__ += ["get_data", "_reset_weights", "ema", "save_checkpoint", "restore_checkpoint", "restore_checkpoint_"]

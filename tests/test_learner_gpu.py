@@ -254,3 +254,31 @@ def test_full_size_update_properties(dev):
     assert all(np.isfinite(v) for v in i1.values())
     assert bool(torch.isfinite(a1.critic.store.flat).all()) and bool(torch.isfinite(a1.actor.store.flat).all())
     assert int(a1.critic.step) == int(agent.critic.step) + U and int(a1.actor.step) == int(agent.actor.step) + 1
+
+
+def test_checkpoint_roundtrip_through_agent(dev, tmp_path):
+    """The reference's save/restore pattern (cable_route_...py:164-170,184-207): save each TrainState with its prefix,
+    restore into a freshly created agent with agent.replace(...): acting and the next update are bit-identical."""
+    from serl_amd.agents import DrQLearner
+    from serl_amd.utils import restore_checkpoint_, save_checkpoint
+    keys = ("wrist_1", "wrist_2")
+    H = W = 32; S = 1
+    obs_space, act_space = pixel_spaces(keys, H, W, S, 19, 7)
+    kw = dict(pixel_keys=keys, num_qs=4, num_min_qs=2, critic_layer_norm=True, backup_entropy=False)
+    rng = np.random.default_rng(0)
+    agent = DrQLearner.create(1, obs_space, act_space, **kw)
+    agent, _ = agent.update(make_pixel_batch(rng, 8, keys, H, W, S, 19, 7, packed=True), 2, pixel_keys=keys)
+    for name in ("actor", "critic", "target_critic", "temp"):
+        save_checkpoint(tmp_path, getattr(agent, name), step=20000, prefix=f"{name}_", keep=1000)
+    fresh = DrQLearner.create(99, obs_space, act_space, **kw)
+    fresh = fresh.replace(rng=agent.rng, **{name: restore_checkpoint_(str(tmp_path / f"{name}_20000"), getattr(fresh, name), None)
+                                            for name in ("actor", "critic", "target_critic", "temp")})
+    ob = {k: rng.integers(0, 256, size=(H, W, 3, S), dtype=np.uint8) for k in keys}
+    ob["state"] = rng.standard_normal(19).astype(np.float32)
+    assert np.array_equal(agent.eval_actions(ob), fresh.eval_actions(ob))
+    batch = make_pixel_batch(rng, 8, keys, H, W, S, 19, 7, packed=True)
+    a1, i1 = agent.update(batch, 2, pixel_keys=keys)
+    a2, i2 = fresh.update(batch, 2, pixel_keys=keys)
+    assert i1 == i2
+    assert torch.equal(a1.critic.store.flat, a2.critic.store.flat) and torch.equal(a1.actor.store.flat, a2.actor.store.flat)
+    assert torch.equal(a1.temp.buf, a2.temp.buf) and a1.critic.step == a2.critic.step
