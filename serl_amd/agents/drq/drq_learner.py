@@ -126,13 +126,16 @@ class DrQLearner(SACLearner):
             nn.trunk_fwd(cfg, tag, store, state.data_ptr() + 4 * lo * cfg.state_dim, ws.ptr(f"z{tag}", (B, ldz)), ldz,
                          B, ws, st_, save=(tag == save_tag))
 
-    def _features_bwd(self, tag, store, grads, feats, lo, B, ws, st, dz_ptr, lddz, need_encoder, gside=None):
+    def _features_bwd(self, tag, store, grads, feats, lo, B, ws, st, dz_ptr, lddz, need_encoder, gside=None,
+                      on_head_grads=None):
         cfg = self._cfg
         ldz = cfg.latent + cfg.action_dim
         which = "obs"
         state = feats["state"]
         nn.trunk_bwd(cfg, tag, store, grads, state.data_ptr() + 4 * lo * cfg.state_dim, ws.ptr(f"z{tag}", (B, ldz)),
                      ldz, dz_ptr, lddz, B, ws, st, need_denc=need_encoder, gside=gside)
+        if on_head_grads is not None:      # every gradient leaf outside image_encoder/* is enqueued now
+            on_head_grads()
         if need_encoder:
             img_bytes = cfg.H * cfg.W * 3 * cfg.stack
             imgs = [feats["aug"][which][cam].data_ptr() + lo * img_bytes for cam in cfg.cams]

@@ -23,6 +23,10 @@ from ...networks.modules import Workspace
 from ...networks.params import ParamStore
 from ...networks.spec import NetConfig, actor_layout, critic_head_prefix, critic_layout, init_tree
 from ..agent import Agent
+import os
+
+DP_OVERLAP = os.environ.get("SERL_AMD_DP_OVERLAP", "1") != "0"   # all-reduce of the head gradients overlapped with the encoder backward
+
 from ..train_state import ADAM_B1, ADAM_B2, ADAM_EPS, TempState, TrainState, bias_corrections
 
 
@@ -162,8 +166,10 @@ class SACLearner(Agent):
             ops.copy2d(ws.ptr(f"z{tag}", (B, ldz)), ldz, src.data_ptr() + 4 * lo * cfg.obs_dim, cfg.obs_dim, B,
                        cfg.obs_dim, st_)
 
-    def _features_bwd(self, tag, store, grads, feats, lo, B, ws, st, dz_ptr, lddz, need_encoder, gside=None):
-        return  # no trainable feature stage for state inputs
+    def _features_bwd(self, tag, store, grads, feats, lo, B, ws, st, dz_ptr, lddz, need_encoder, gside=None,
+                      on_head_grads=None):
+        if on_head_grads is not None:      # no trainable feature stage for state inputs: all gradients are enqueued
+            on_head_grads()
 
     # ------------------------------------------------------------------ update
     def update(self, batch, utd_ratio: int):
@@ -241,11 +247,28 @@ class SACLearner(Agent):
             gside.begin()
             dinp = nn.ensemble_bwd(cfg, "C", critic.store, cgr, dq, zC, ldz, B, ws, st, gside=gside)
             ops.phase("ensemble_bwd")
-            self._features_bwd("C", critic.store, cgr, feats, lo, B, ws, st, dinp, ldz, need_encoder=True, gside=gside)
+            # data parallel: the head / trunk gradient leaves (everything behind the image_encoder/* prefix of the flat
+            # buffer) are complete before the conv backward starts; their all-reduce runs behind the side stream's
+            # kernels while the encoder backward proceeds, only the encoder prefix is reduced on the critical path
+            head_work = []
+            enc_n = critic.store.layout.prefix_size("image_encoder") if DP_OVERLAP else 0
+
+            def reduce_heads():
+                if dist is not None and DP_OVERLAP:
+                    head_work.append(dist.all_reduce_sum_async(cgr.flat[enc_n:], gside.side))
+            self._features_bwd("C", critic.store, cgr, feats, lo, B, ws, st, dinp, ldz, need_encoder=True, gside=gside,
+                               on_head_grads=reduce_heads)
             gside.join()
             ops.phase("features_bwd")
             if dist is not None:
-                dist.all_reduce_sum(cgr.flat)
+                if not DP_OVERLAP:
+                    dist.all_reduce_sum(cgr.flat)
+                else:
+                    if enc_n:
+                        dist.all_reduce_sum(cgr.flat[:enc_n])
+                    for w in head_work:
+                        if w is not None:
+                            w.wait()
             critic.step += 1
             bc1, bc2 = bias_corrections(critic.step)
             ops.adam_polyak(critic.store.base, critic.mu.data_ptr(), critic.nu.data_ptr(), cgr.base,
