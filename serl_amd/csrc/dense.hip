@@ -7,6 +7,10 @@
 //   with k = seg*seglen + r  (segments let one GEMM reduce over (member, feature) pairs).
 #include "igemm_bf3.h"
 
+#ifndef GEMM_DEPTH
+#define GEMM_DEPTH 1   // K-steps of register prefetch of the small-tile bf16_3x kernel (igemm_bf3.h); 2 measured neutral, 3 spills
+#endif
+
 struct GemmArgs {
   const float* a; const float* b; float* c; const float* bias;
   int M, N, K, seglen;
@@ -118,7 +122,7 @@ extern "C" int serl_gemm(const float* a, const float* b, float* c, const float* 
   {                                                                                                         \
     GemmP<AK, BN, VA, VB> p; p.g = g;                                                                       \
     return big ? igemm_launch_prec<GemmP<AK, BN, VA, VB>, T128x128, B128x128>(p, M, N, nsplit, nbatch, st, "gemm") \
-               : igemm_launch_prec<GemmP<AK, BN, VA, VB>, T64x64, B64x64>(p, M, N, nsplit, nbatch, st, "gemm");  \
+               : igemm_launch_prec<GemmP<AK, BN, VA, VB>, T64x64, B64x64, GEMM_DEPTH>(p, M, N, nsplit, nbatch, st, "gemm");  \
   }
 #define GO(AK, BN)                     \
   {                                    \

@@ -30,8 +30,11 @@ __device__ __forceinline__ void split_pair(float a, float b, uint32_t& hi, uint3
   lo = pack_bf16_rn(a - ha, b - hb);
 }
 
-template <class P, class T>
+// D = K-steps of register prefetch: the launches of the dense layers are a handful of blocks walking a long K loop, and
+// with one step in flight every K-step costs a full memory round trip (~2 us); D = 3 keeps three steps in flight.
+template <class P, class T, int D = 1>
 __global__ __launch_bounds__(256, 2) void igemm_bf3_kernel(const P p) {
+  static_assert(D >= 1 && D <= 3, "prefetch depth");
   constexpr int BM = T::BM, BN = T::BN, BK = T::BK, TM = T::TM, TN = T::TN;
   static_assert(BK % 16 == 0, "bf16 MFMA consumes K in steps of 16");
   static_assert(T::NT == 256, "igemm_bf3_kernel runs 4 waves");
@@ -99,10 +102,13 @@ __global__ __launch_bounds__(256, 2) void igemm_bf3_kernel(const P p) {
   const bool a_on = (NA * A_STEP == A_EXT) || ((AKC ? a_ml : a_kl) < A_EXT);
   const bool b_on = (NB * B_STEP == B_EXT) || ((BKC ? b_nl : b_kl) < B_EXT);
 
-  VecF<VA> areg[NA][AKP], aadd[NA][AKP];
-  VecF<VB> breg[NB][BKP];
-  float amul[NA][AKP], bmul[NB][BKP];
-  auto gload = [&](int k0) {
+  VecF<VA> areg_[D][NA][AKP], aadd_[D][NA][AKP];
+  VecF<VB> breg_[D][NB][BKP];
+  float amul_[D][NA][AKP], bmul_[D][NB][BKP];
+  auto gload = [&](auto set_tag, int k0) {
+    auto& areg = areg_[decltype(set_tag)::value]; auto& aadd = aadd_[decltype(set_tag)::value];
+    auto& breg = breg_[decltype(set_tag)::value];
+    auto& amul = amul_[decltype(set_tag)::value]; auto& bmul = bmul_[decltype(set_tag)::value];
     if (a_on) {
       if constexpr (AKC) {
         typename P::AK ak;
@@ -170,7 +176,10 @@ __global__ __launch_bounds__(256, 2) void igemm_bf3_kernel(const P p) {
       d[part] = lo[0];
     }
   };
-  auto lstore = [&](int buf) {
+  auto lstore = [&](auto set_tag, int buf) {
+    auto& areg = areg_[decltype(set_tag)::value]; auto& aadd = aadd_[decltype(set_tag)::value];
+    auto& breg = breg_[decltype(set_tag)::value];
+    auto& amul = amul_[decltype(set_tag)::value]; auto& bmul = bmul_[decltype(set_tag)::value];
     uint32_t* As_ = As + buf * (2 * A_PART);
     uint32_t* Bs_ = Bs + buf * (2 * B_PART);
     if (a_on) {
@@ -218,14 +227,7 @@ __global__ __launch_bounds__(256, 2) void igemm_bf3_kernel(const P p) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
-  gload(kbeg);
-  lstore(0);
-  __syncthreads();
-  int cur = 0;
-  for (int k0 = kbeg; k0 < kend; k0 += BK) {
-    const bool more = (k0 + BK) < kend;
-    if (more) gload(k0 + BK);
-    __builtin_amdgcn_sched_barrier(0);
+  auto mma = [&](int cur) {
     const uint32_t* Ah = As + cur * (2 * A_PART);
     const uint32_t* Bh = Bs + cur * (2 * B_PART);
 #pragma unroll
@@ -250,10 +252,57 @@ __global__ __launch_bounds__(256, 2) void igemm_bf3_kernel(const P p) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
     }
-    __builtin_amdgcn_sched_barrier(0);
-    if (more) lstore(cur ^ 1);
+  };
+  constexpr std::integral_constant<int, 0> S0{};
+  if constexpr (D == 1) {
+    gload(S0, kbeg);
+    lstore(S0, 0);
     __syncthreads();
-    cur ^= 1;
+    int cur = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+      const bool more = (k0 + BK) < kend;
+      if (more) gload(S0, k0 + BK);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(cur);
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) lstore(S0, cur ^ 1);
+      __syncthreads();
+      cur ^= 1;
+    }
+  } else {
+    // Register set j holds K-step (t + j) mod D.  Loads are unconditional (a step past kend reads element 0 with a
+    // zero multiplier), so the code is straight-line and hipcc counts vmcnt exactly: writing step t+1 to LDS waits
+    // for its own loads only, the loads of t+2 .. t+D stay in flight.
+    constexpr std::integral_constant<int, 1> S1{};
+    constexpr std::integral_constant<int, (D > 2 ? 2 : 0)> S2{};
+    gload(S0, kbeg);
+    gload(S1, kbeg + BK);
+    if constexpr (D > 2) gload(S2, kbeg + 2 * BK);
+    lstore(S0, 0);
+    __syncthreads();
+    int cur = 0, k0 = kbeg;
+    auto step = [&](auto jt, auto jn) -> bool {
+      gload(jt, k0 + D * BK);                  // set jt was written to LDS one step ago: free
+      __builtin_amdgcn_sched_barrier(0);
+      mma(cur);
+      __builtin_amdgcn_sched_barrier(0);
+      lstore(jn, cur ^ 1);
+      __syncthreads();
+      cur ^= 1;
+      k0 += BK;
+      return k0 < kend;
+    };
+    if (k0 < kend) {
+      while (true) {
+        if (!step(S0, S1)) break;
+        if constexpr (D == 2) {
+          if (!step(S1, S0)) break;
+        } else {
+          if (!step(S1, S2)) break;
+          if (!step(S2, S0)) break;
+        }
+      }
+    }
   }
   igemm_epilogue<P, T>(p, ctx, acc, M, N, m0, n0, wm, wn, r, h, split);
 }
@@ -270,7 +319,7 @@ constexpr int bf3_lds_bytes() {
 }
 
 // T: tile of the fp32 kernel, TB: tile of the bf16_3x kernel (deeper K slab: more bytes in flight per block)
-template <class P, class T, class TB = T>
+template <class P, class T, class TB = T, int D = 1>
 static inline int igemm_launch_prec(const P& p, int max_m, int max_n, int nsplit, int nz, hipStream_t st, const char* name) {
   if (serl_get_matmul_precision() == 0) return igemm_launch<P, T>(p, max_m, max_n, nsplit, nz, st, name);
   const int tiles = cdiv(max_m, TB::BM) * cdiv(max_n, TB::BN);
@@ -282,11 +331,11 @@ static inline int igemm_launch_prec(const P& p, int max_m, int max_n, int nsplit
   int dev = 0;
   SERL_CHECK_HIP(hipGetDevice(&dev), name);
   if (lds > 48 * 1024 && dev >= 0 && dev < 64 && !opted[dev]) {
-    SERL_CHECK_HIP(hipFuncSetAttribute((const void*)igemm_bf3_kernel<P, TB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds), name);
+    SERL_CHECK_HIP(hipFuncSetAttribute((const void*)igemm_bf3_kernel<P, TB, D>, hipFuncAttributeMaxDynamicSharedMemorySize, lds), name);
     opted[dev] = true;
   }
   dim3 grid(tiles, nsplit, nz);
-  hipLaunchKernelGGL((igemm_bf3_kernel<P, TB>), grid, dim3(256), lds, st, p);
+  hipLaunchKernelGGL((igemm_bf3_kernel<P, TB, D>), grid, dim3(256), lds, st, p);
   SERL_CHECK_LAUNCH(name);
   return SERL_OK;
 }
