@@ -25,6 +25,9 @@ from ...networks.spec import NetConfig, actor_layout, critic_head_prefix, critic
 from ..agent import Agent
 import os
 
+# the actor's no-grad pass over next_obs (constant parameters during a call) runs ahead on its own stream
+ACTOR_RUNAHEAD = os.environ.get("SERL_AMD_ACTOR_RUNAHEAD", "1") != "0"
+ACTOR_GATE = os.environ.get("SERL_AMD_ACTOR_GATE", "1") != "0"
 DP_OVERLAP = os.environ.get("SERL_AMD_DP_OVERLAP", "1") != "0"   # all-reduce of the head gradients overlapped with the encoder backward
 
 from ..train_state import ADAM_B1, ADAM_B2, ADAM_EPS, TempState, TrainState, bias_corrections
@@ -111,7 +114,8 @@ class SACLearner(Agent):
         if ss is None:
             ss = self._shared["side_streams"] = dict(
                 s=[torch.cuda.Stream(), torch.cuda.Stream()],
-                fork=torch.cuda.Event(), join=[torch.cuda.Event(), torch.cuda.Event()])
+                fork=torch.cuda.Event(), join=[torch.cuda.Event(), torch.cuda.Event()],
+                actor=torch.cuda.Stream(), astart=torch.cuda.Event(), agate=torch.cuda.Event(), adone=[])
         return ss
 
     def _target_members(self, key):
@@ -206,30 +210,74 @@ class SACLearner(Agent):
         log_temp = temp.buf.data_ptr()
         rng = self.rng
 
+        # rng chain of the UTD loop (sac_learner.py:166-209): four splits per critic step, known up front
+        step_keys = []
         for i in range(utd_ratio):
-            lo = i * B
-            ops.phase("step")
-            # ---- critic step (sac_learner.py:160-219)
             key_act, rng = prng.split(rng)
             key_sub, rng = prng.split(rng)
             _, rng = prng.split(rng)                       # target dropout key (consumed, unused)
             _, rng = prng.split(rng)                       # critic dropout key
+            step_keys.append((key_act, key_sub))
+        ss = self._side_streams()
+        main = torch.cuda.current_stream()
+        s0, s1 = ss["s"]
+        next_act = nlogp_all = None
+        if ACTOR_RUNAHEAD:
+            # The actor's parameters do not change inside the UTD loop (its step comes after it, :235), so its
+            # pass over next_obs -- encoder, trunk, policy sample: a third of the forward conv work -- does not
+            # depend on the critic steps.  It runs for all U minibatches on its own stream, ahead of the loop, and
+            # fills the HBM bandwidth the latency-bound head / TD / dense-backward phases of the main stream leave idle.
+            astream, adone = ss["actor"], ss["adone"]
+            while len(adone) < utd_ratio:
+                adone.append(torch.cuda.Event())
+            ss["astart"].record(main)
+            astream.wait_event(ss["astart"])
+            next_act = ws.ptr("next_act_all", (utd_ratio, B, A))
+            nlogp_all = ws.ptr("nlogp_all", (utd_ratio, B))
+            sta = astream.cuda_stream
+
+            def enqueue_actor(j):
+                self._features([("A", actor.store, "next")], feats, j * B, B, ws, sta)
+                nn.policy_fwd(cfg, "A", actor.store, zA, ldz, B, ws, sta, step_keys[j][0], rank * B, Bg,
+                              next_act + 4 * j * B * A, A, want_logp=self.backup_entropy,
+                              logp_out=nlogp_all + 4 * j * B)
+                adone[j].record(astream)
+            # the host interleaves the two streams' launches (pass j+1 is enqueued inside critic step j): enqueued all
+            # up front, the main stream would sit empty while the host is busy with the actor stream's 500 launches
+            enqueue_actor(0)
+
+        for i in range(utd_ratio):
+            lo = i * B
+            ops.phase("step")
+            # ---- critic step (sac_learner.py:160-219)
+            key_act, key_sub = step_keys[i]
             m0, mstride, emin, idx = self._target_members(key_sub)
             tstore = target.store
             if m0 is None:
                 tstore, m0, mstride = self._gathered_target(idx, target.store), 0, 1
-            # encoders of the three passes in grouped launches on the main stream, then three concurrent chains:
-            #   main: actor trunk + policy (next action -> zT)      side 0: target trunk      side 1: critic trunk + Q
-            ss = self._side_streams()
-            main = torch.cuda.current_stream()
-            s0, s1 = ss["s"]
-            self._features([("A", actor.store, "next"), ("T", target.store, "next"), ("C", critic.store, "obs")],
-                           feats, lo, B, ws, st, save_tag="C", trunk_streams={"T": s0, "C": s1}, fork=ss["fork"])
-            ops.phase("features_fwd")
-            nlogp = nn.policy_fwd(cfg, "A", actor.store, zA, ldz, B, ws, st, key_act, rank * B, Bg,
-                                  zT + 4 * cfg.latent, ldz, want_logp=self.backup_entropy)
-            ss["join"][0].record(s0)
-            main.wait_event(ss["join"][0])
+            if ACTOR_RUNAHEAD:
+                # target chain on the main stream, critic chain on a side stream, next action from the actor stream
+                self._features([("T", target.store, "next"), ("C", critic.store, "obs")],
+                               feats, lo, B, ws, st, save_tag="C", trunk_streams={"C": s1}, fork=ss["fork"])
+                ops.phase("features_fwd")
+                if i + 1 < utd_ratio:
+                    if ACTOR_GATE:       # start pass i+1 when the main stream leaves its (HBM-bound) encoder forward
+                        ss["agate"].record(main)
+                        astream.wait_event(ss["agate"])
+                    enqueue_actor(i + 1)
+                main.wait_event(ss["adone"][i])
+                ops.copy2d(zT + 4 * cfg.latent, ldz, next_act + 4 * i * B * A, A, B, A, st)
+                nlogp = nlogp_all + 4 * i * B if self.backup_entropy else None
+            else:
+                # encoders of the three passes in grouped launches on the main stream, then three concurrent chains:
+                #   main: actor trunk + policy (next action -> zT)      side 0: target trunk      side 1: critic trunk + Q
+                self._features([("A", actor.store, "next"), ("T", target.store, "next"), ("C", critic.store, "obs")],
+                               feats, lo, B, ws, st, save_tag="C", trunk_streams={"T": s0, "C": s1}, fork=ss["fork"])
+                ops.phase("features_fwd")
+                nlogp = nn.policy_fwd(cfg, "A", actor.store, zA, ldz, B, ws, st, key_act, rank * B, Bg,
+                                      zT + 4 * cfg.latent, ldz, want_logp=self.backup_entropy)
+                ss["join"][0].record(s0)
+                main.wait_event(ss["join"][0])
             next_q = nn.ensemble_fwd(cfg, "T", tstore, m0, mstride, emin, zT, ldz, B, ws, st, save=False)
             st1 = s1.cuda_stream
             ops.copy2d(zC + 4 * cfg.latent, ldz, actions.data_ptr() + 4 * lo * A, A, B, A, st1)

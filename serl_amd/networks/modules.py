@@ -339,8 +339,9 @@ def ensemble_bwd(cfg: NetConfig, tag, store, grads, dq_ptr, inp_ptr, ld_inp, B, 
 
 # =============================================================================== policy head
 def policy_fwd(cfg: NetConfig, tag, store, z_ptr, ldz, B, ws: Workspace, st, key, row_offset, total_rows,
-               act_ptr, ld_act, deterministic=False, save=False, want_logp=True):
-    """TanhNormal(MLP) on z (B, latent): writes actions to act_ptr (row stride ld_act); returns ptr of logp (B,)."""
+               act_ptr, ld_act, deterministic=False, save=False, want_logp=True, logp_out=None):
+    """TanhNormal(MLP) on z (B, latent): writes actions to act_ptr (row stride ld_act); returns ptr of logp (B,)
+    (`logp_out` when given, else a workspace buffer of the pass)."""
     pre = actor_head_prefix(cfg)
     A = cfg.action_dim
     a_ptr, a_ms, din = z_ptr, ldz, cfg.latent
@@ -355,7 +356,7 @@ def policy_fwd(cfg: NetConfig, tag, store, z_ptr, ldz, B, ws: Workspace, st, key
     bm, bl = store.ptr(*pre, "OutputDenseMean", "bias"), store.ptr(*pre, "OutputDenseLogStd", "bias")
     ops.gemm(a_ptr, wm, ms, bm, 2, B, A, din, a_zs=0, a_ms=a_ms, a_ks=1, b_zs=(wl - wm) // 4, b_ks=A, b_ns=1,
              c_zs=A, c_ms=2 * A, bias_zs=(bl - bm) // 4, stream=st)
-    logp = ws.ptr(f"logp_{tag}", (B,)) if want_logp else None
+    logp = (logp_out if logp_out is not None else ws.ptr(f"logp_{tag}", (B,))) if want_logp else None
     ops.tanh_gaussian_fwd(ms, ms + 4 * A, 2 * A, act_ptr, ld_act, None,
                           ws.ptr(f"eps_{tag}", (B, A)) if save else None, logp, B, A,
                           key if key is not None else (0, 0), row_offset, total_rows, deterministic, st)
