@@ -61,7 +61,9 @@ class DrQLearner(SACLearner):
 
     # ------------------------------------------------------------------ augmentation + unpack + gather
     def _augment(self, batch, n, key_obs, key_next, ws):
-        """Returns {'obs'|'next': [u8 (n,H,W,3S) device tensor per camera in cfg.cams order]}.
+        """Returns ({'obs'|'next': [u8 (n,H,W,3S) device tensor per camera in cfg.cams order]}, crop) where
+        crop(lo, rows, stream) launches the fused gather + _unpack + random-shift kernels for rows [lo, lo+rows)
+        of every (side, camera); the per-row offsets are computed here, for all rows.
         data_augmentation_fn: per pixel key (caller order) key, rng = split(rng); crop with `key`."""
         cfg = self._cfg
         dev = self.actor.store.flat.device
@@ -71,7 +73,9 @@ class DrQLearner(SACLearner):
         world = dist.world_size if dist is not None else 1
         rank = dist.rank if dist is not None else 0
         out = {"obs": {}, "next": {}}
+        jobs = []
         obs, nxt = batch["observations"], batch["next_observations"]
+        img = H * W * 3 * S
         for side, rng, t0 in (("obs", key_obs, 0), ("next", key_next, 1)):
             for cam in cfg.pixel_keys:                                   # augmentation key order = pixel_keys
                 key, rng = prng.split(rng)
@@ -88,8 +92,10 @@ class DrQLearner(SACLearner):
                 packed = cam not in nxt
                 src = obs[cam] if (side == "obs" or packed) else nxt[cam]
                 if isinstance(src, FrameWindows):
-                    ops.gather_crop_frames(src.frames.data_ptr(), src.capacity, src.indx.data_ptr(), S + 1, t0,
-                                           off.data_ptr(), dst.data_ptr(), n, H, W, S, PAD, st)
+                    def job(lo, rows, stream, src=src, off=off, dst=dst, t0=t0):
+                        ops.gather_crop_frames(src.frames.data_ptr(), src.capacity, src.indx.data_ptr() + 8 * lo, S + 1,
+                                               t0, off.data_ptr() + 8 * lo, dst.data_ptr() + lo * img, rows, H, W, S,
+                                               PAD, stream)
                 else:
                     T = S + 1 if packed else S
                     if isinstance(src, torch.Tensor):
@@ -99,10 +105,17 @@ class DrQLearner(SACLearner):
                         if side == "obs" or not packed:
                             s_dev.copy_(torch.from_numpy(np.ascontiguousarray(src)))
                     assert tuple(s_dev.shape) == (n, H, W, 3, T), f"{cam}: {tuple(s_dev.shape)} != {(n, H, W, 3, T)}"
-                    ops.gather_crop_packed(s_dev.data_ptr(), T, t0 if packed else 0, off.data_ptr(), dst.data_ptr(), n,
-                                           H, W, S, PAD, st)
+
+                    def job(lo, rows, stream, s_dev=s_dev, off=off, dst=dst, T=T, t0=(t0 if packed else 0)):
+                        ops.gather_crop_packed(s_dev.data_ptr() + lo * H * W * 3 * T, T, t0, off.data_ptr() + 8 * lo,
+                                               dst.data_ptr() + lo * img, rows, H, W, S, PAD, stream)
+                jobs.append(job)
                 out[side][cam] = dst
-        return out
+
+        def crop(lo, rows, stream):
+            for job in jobs:
+                job(lo, rows, stream)
+        return out, crop
 
     def _prepare(self, batch, n):
         raise RuntimeError("DrQLearner prepares features inside update()")
@@ -160,8 +173,8 @@ class DrQLearner(SACLearner):
         # rng, key = split(rng) -- note: rng is child 0 here (drq_learner.py:174,176)
         rng, key_obs = prng.split(self.rng)
         rng, key_next = prng.split(rng)
-        aug = self._augment(batch, n, key_obs, key_next, ws)
-        feats = dict(aug=aug,
+        aug, crop = self._augment(batch, n, key_obs, key_next, ws)
+        feats = dict(aug=aug, crop=crop,
                      state=_to_dev(batch["observations"]["state"], dev, f32).reshape(n, cfg.state_dim),
                      next_state=_to_dev(batch["next_observations"]["state"], dev, f32).reshape(n, cfg.state_dim))
         return self.replace(rng=rng)._update_prepared(batch, feats, n, utd_ratio, actor)

@@ -11,6 +11,7 @@ All tensor math runs in hand-written HIP kernels (serl_amd.ops); Python only seq
 """
 from __future__ import annotations
 
+from collections.abc import Mapping
 from typing import Optional, Sequence
 
 import numpy as np
@@ -27,6 +28,9 @@ import os
 
 # the actor's no-grad pass over next_obs (constant parameters during a call) runs ahead on its own stream
 ACTOR_RUNAHEAD = os.environ.get("SERL_AMD_ACTOR_RUNAHEAD", "1") != "0"
+# augment minibatch j+1 on the run-ahead stream during critic step j instead of all rows up front: measured neutral
+# (the idle windows are already full with the actor pass), off by default
+CHUNKED_CROP = os.environ.get("SERL_AMD_CHUNKED_CROP", "0") != "0"
 ACTOR_GATE = os.environ.get("SERL_AMD_ACTOR_GATE", "1") != "0"
 DP_OVERLAP = os.environ.get("SERL_AMD_DP_OVERLAP", "1") != "0"   # all-reduce of the head gradients overlapped with the encoder backward
 
@@ -45,6 +49,40 @@ def _to_dev(x, dev, dtype):
     if isinstance(x, torch.Tensor):
         return x.to(device=dev, dtype=dtype).contiguous()
     return torch.from_numpy(np.ascontiguousarray(np.asarray(x), dtype=None)).to(dev).to(dtype).contiguous()
+
+
+class UpdateInfo(Mapping):
+    """The logged scalars of one update() call.  Like the jax Arrays the reference returns (sac_learner.py:238), the
+    values are device results of asynchronously enqueued work: update() returns without waiting for the GPU and the
+    first access (indexing, iteration over items, comparison, dict(info)) copies the 8 floats to the host."""
+    KEYS = ("actor_loss", "entropy", "critic_loss", "q", "temperature", "temperature_loss")
+
+    def __init__(self, dev_scalars, global_batch, num_qs):
+        self._dev, self._bg, self._e, self._host = dev_scalars, global_batch, num_qs, None
+
+    def _materialize(self):
+        if self._host is None:
+            h = self._dev.cpu().numpy()                      # one small D2H per update call, on first access
+            bg, e = self._bg, self._e
+            self._host = {
+                "actor_loss": float(h[2]) / bg, "entropy": float(h[6]),
+                "critic_loss": float(h[0]) / (e * bg), "q": float(h[1]) / (e * bg),
+                "temperature": float(h[4]), "temperature_loss": float(h[5]),
+            }
+            self._dev = None
+        return self._host
+
+    def __getitem__(self, k):
+        return self._materialize()[k]
+
+    def __iter__(self):
+        return iter(self.KEYS)
+
+    def __len__(self):
+        return len(self.KEYS)
+
+    def __repr__(self):
+        return repr(self._materialize())
 
 
 class SACLearner(Agent):
@@ -115,7 +153,7 @@ class SACLearner(Agent):
             ss = self._shared["side_streams"] = dict(
                 s=[torch.cuda.Stream(), torch.cuda.Stream()],
                 fork=torch.cuda.Event(), join=[torch.cuda.Event(), torch.cuda.Event()],
-                actor=torch.cuda.Stream(), astart=torch.cuda.Event(), agate=torch.cuda.Event(), adone=[])
+                actor=torch.cuda.Stream(), astart=torch.cuda.Event(), agate=torch.cuda.Event(), adone=[], cdone=[])
         return ss
 
     def _target_members(self, key):
@@ -222,14 +260,21 @@ class SACLearner(Agent):
         main = torch.cuda.current_stream()
         s0, s1 = ss["s"]
         next_act = nlogp_all = None
+        # pixel learners: fused gather + crop of the minibatch rows (feats["crop"]).  With the run-ahead stream only the
+        # first minibatch is augmented up front; minibatch j+1 is augmented on that stream during critic step j.
+        crop = feats.get("crop")
+        chunked_crop = crop is not None and ACTOR_RUNAHEAD and CHUNKED_CROP and utd_ratio > 1
+        if crop is not None:
+            crop(0, B if chunked_crop else n, st)
         if ACTOR_RUNAHEAD:
             # The actor's parameters do not change inside the UTD loop (its step comes after it, :235), so its
             # pass over next_obs -- encoder, trunk, policy sample: a third of the forward conv work -- does not
             # depend on the critic steps.  It runs for all U minibatches on its own stream, ahead of the loop, and
             # fills the HBM bandwidth the latency-bound head / TD / dense-backward phases of the main stream leave idle.
-            astream, adone = ss["actor"], ss["adone"]
+            astream, adone, cdone = ss["actor"], ss["adone"], ss["cdone"]
             while len(adone) < utd_ratio:
                 adone.append(torch.cuda.Event())
+                cdone.append(torch.cuda.Event())
             ss["astart"].record(main)
             astream.wait_event(ss["astart"])
             next_act = ws.ptr("next_act_all", (utd_ratio, B, A))
@@ -237,6 +282,9 @@ class SACLearner(Agent):
             sta = astream.cuda_stream
 
             def enqueue_actor(j):
+                if chunked_crop and j > 0:
+                    crop(j * B, B, sta)
+                    cdone[j].record(astream)
                 self._features([("A", actor.store, "next")], feats, j * B, B, ws, sta)
                 nn.policy_fwd(cfg, "A", actor.store, zA, ldz, B, ws, sta, step_keys[j][0], rank * B, Bg,
                               next_act + 4 * j * B * A, A, want_logp=self.backup_entropy,
@@ -257,6 +305,8 @@ class SACLearner(Agent):
                 tstore, m0, mstride = self._gathered_target(idx, target.store), 0, 1
             if ACTOR_RUNAHEAD:
                 # target chain on the main stream, critic chain on a side stream, next action from the actor stream
+                if chunked_crop and i > 0:
+                    main.wait_event(ss["cdone"][i])
                 self._features([("T", target.store, "next"), ("C", critic.store, "obs")],
                                feats, lo, B, ws, st, save_tag="C", trunk_streams={"C": s1}, fork=ss["fork"])
                 ops.phase("features_fwd")
@@ -358,10 +408,5 @@ class SACLearner(Agent):
 
         ops.phase("end")
         new_agent = self.replace(actor=actor, critic=critic, target_critic=target, temp=temp, rng=rng)
-        h = info.cpu().numpy()                              # one small D2H per update call
-        out = {
-            "actor_loss": float(h[2]) / Bg, "entropy": float(h[6]),
-            "critic_loss": float(h[0]) / (E * Bg), "q": float(h[1]) / (E * Bg),
-            "temperature": float(h[4]), "temperature_loss": float(h[5]),
-        }
-        return new_agent, out
+        snap = info.clone()         # `info` is workspace memory: the next update() call overwrites it
+        return new_agent, UpdateInfo(snap, Bg, E)

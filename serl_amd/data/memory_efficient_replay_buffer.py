@@ -154,7 +154,7 @@ class MemoryEfficientReplayBuffer(ReplayBuffer):
         batch, _ = self._non_pixel(indx, args.pop("keys", None))
         assert not args, f"unknown sample args {sorted(args)}"
         out = to_device(batch, dev).unfreeze()
-        ix = torch.from_numpy(indx.astype(np.int64)).to(self._device)
+        ix = torch.from_numpy(indx.astype(np.int64)).pin_memory().to(self._device, non_blocking=True)
         for k in self.pixel_keys:
             out["observations"][k] = FrameWindows(self._frames[k], self._capacity, ix, self._num_stack)
         return freeze(out)

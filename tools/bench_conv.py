@@ -11,6 +11,7 @@ from serl_amd import ops  # noqa: E402
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 ONLY = os.environ.get("BENCH_ONLY", "")        # e.g. "conv3 fwd,conv2 dgrad": run only these launches
 NITER = int(os.environ.get("BENCH_N", "20"))
+FWD_G = int(os.environ.get("BENCH_FWD_G", "4"))   # forward groups per launch: 2 cameras x (target, critic) passes
 MODE = os.environ.get("BENCH_MODE", "s")         # "s": S-format entry points (serl_convs_*); "f": serl_conv2d_*
 dev = torch.device("cuda")
 LAYERS = [(128, 9, 32), (63, 32, 64), (31, 64, 128), (15, 128, 256)]   # IH, C, F  (3x3, stride 2)
@@ -31,7 +32,7 @@ tot = 0.0
 for li, (IH, C, F) in enumerate(LAYERS):
     OH = (IH - 3) // 2 + 1
     flop1 = 2.0 * B * OH * OH * F * 9 * C
-    for G, what in ((6, "fwd"), (2, "wgrad"), (2, "dgrad")):
+    for G, what in ((FWD_G, "fwd"), (2, "wgrad"), (2, "dgrad")):
         if what == "dgrad" and li == 0:
             continue
         if ONLY and f"conv{li + 1} {what}" not in ONLY.split(","):
@@ -61,7 +62,7 @@ for li, (IH, C, F) in enumerate(LAYERS):
             yS = [torch.empty(B * OH * OH * F * 2, dtype=torch.int16, device=dev) for _ in range(G)]
             if what == "fwd":
                 rm = None
-                if os.environ.get("BENCH_RMASK"):     # 2 of the 6 groups (the critic pass) write ReLU byte masks
+                if not os.environ.get("BENCH_NO_RMASK"):     # 2 of the groups (the critic pass) write ReLU byte masks
                     rmt = [torch.empty(B * OH * OH * F // 8, dtype=torch.uint8, device=dev) for _ in range(2)]
                     rm = p(rmt) + [0] * (G - 2)
                 fn = lambda: ops.convs_fwd(p(xS), p(wf), p(bs), p(yS), u8, B, IH, IH, C, 3, 3, 2, F, True, st, rmasks=rm)
@@ -73,7 +74,7 @@ for li, (IH, C, F) in enumerate(LAYERS):
                                              2, F, st)
             else:
                 dxS = [torch.empty(B * IH * IH * C * 2, dtype=torch.int16, device=dev) for _ in range(G)]
-                if os.environ.get("BENCH_BITMASK"):
+                if not (os.environ.get("BENCH_HIMASK") or os.environ.get("BENCH_NOMASK")):     # as the learner: byte masks
                     bm = [torch.randint(0, 256, (B * IH * IH * C // 8,), dtype=torch.uint8, device="cuda") for _ in range(G)]
                     fn = lambda: ops.convs_dgrad(p(dzS), p(wd), p(bm), p(dxS), B, IH, IH, C, 3, 3, 2, F, st, xact_bits=True)
                 else:
@@ -93,4 +94,4 @@ for li, (IH, C, F) in enumerate(LAYERS):
         per_step = ms * (1 if what == "fwd" else 1)
         tot += per_step
         print(f"conv{li + 1} {what:5s} G={G}: {ms * 1e3:8.1f} us  {flop1 * G / ms / 1e9:7.1f} TFLOP/s")
-print(f"sum of one fwd(6 groups)+wgrad+dgrad per layer: {tot:.3f} ms per grad-step (ideal {301e9 / 157.3e12 * 1e3:.2f})")
+print(f"sum of one fwd({FWD_G} groups)+wgrad+dgrad per layer: {tot:.3f} ms per grad-step (ideal {301e9 / 157.3e12 * 1e3:.2f})")

@@ -3,11 +3,13 @@
 # rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs (MI355X_MICROARCH.md, HBM section), one
 # launch configuration per run (tools/bench_conv.py, BENCH_ONLY), averaged over the dispatches of the run.
 OUT=$1
-OPS="conv1_fwd conv1_wgrad conv2_fwd conv2_wgrad conv2_dgrad conv3_fwd conv3_wgrad conv3_dgrad conv4_fwd conv4_wgrad conv4_dgrad"
+# <layer>_<op>@<groups>: forward launches carry 4 groups (target + critic passes) or 2 (actor run-ahead pass)
+OPS="conv1_fwd@4 conv1_fwd@2 conv1_wgrad@2 conv2_fwd@4 conv2_fwd@2 conv2_wgrad@2 conv2_dgrad@2 conv3_fwd@4 conv3_fwd@2 conv3_wgrad@2 conv3_dgrad@2 conv4_fwd@4 conv4_fwd@2 conv4_wgrad@2 conv4_dgrad@2"
 CMD="mkdir -p gpurun_out/traffic && cd /tmp && export TMPDIR=/tmp && export BENCH_N=2"
-for OP in $OPS; do
+for OPG in $OPS; do
+  OP=${OPG%@*}; G=${OPG#*@}
   for P in FETCH_SIZE WRITE_SIZE; do
-    CMD="$CMD && BENCH_ONLY='${OP/_/ }' timeout -s KILL 120 rocprofv3 --pmc $P --output-format csv -d \$GRAFT_REPO_ROOT/gpurun_out/traffic/${OP}_$P -- python3 \$GRAFT_REPO_ROOT/tools/bench_conv.py > \$GRAFT_REPO_ROOT/gpurun_out/traffic/${OP}_$P.out 2>&1"
+    CMD="$CMD && BENCH_FWD_G=$G BENCH_ONLY='${OP/_/ }' timeout -s KILL 120 rocprofv3 --pmc $P --output-format csv -d \$GRAFT_REPO_ROOT/gpurun_out/traffic/${OP}_g${G}_$P -- python3 \$GRAFT_REPO_ROOT/tools/bench_conv.py > \$GRAFT_REPO_ROOT/gpurun_out/traffic/${OP}_g${G}_$P.out 2>&1"
   done
 done
 rm -rf gpurun_out/traffic
@@ -16,7 +18,7 @@ python3 - "$OUT" <<'PY'
 import csv, glob, json, sys
 out = {}
 for d in sorted(glob.glob("gpurun_out/traffic/*_FETCH_SIZE")) + sorted(glob.glob("gpurun_out/traffic/*_WRITE_SIZE")):
-    op, counter = d.split("/")[-1].rsplit("_", 2)[0], "_".join(d.split("/")[-1].rsplit("_", 2)[1:])
+    op, counter = d.split("/")[-1].rsplit("_", 2)[0], "_".join(d.split("/")[-1].rsplit("_", 2)[1:])   # conv1_fwd_g4
     vals, name = [], None
     for f in glob.glob(d + "/*/*counter_collection.csv"):
         for r in csv.DictReader(open(f)):
@@ -29,7 +31,7 @@ for op, e in out.items():
     # gfx950: FETCH_SIZE tallies the 128-byte requests of wide (16 B/lane) loads at 64 B -> double it; WRITE_SIZE is exact
     e["hbm_side_bytes"] = 2 * 1024 * e.get("FETCH_SIZE_KB", 0) + 1024 * e.get("WRITE_SIZE_KB", 0)
 json.dump({"note": "L2-miss (fabric-side) bytes per launch: 2 x FETCH_SIZE + WRITE_SIZE (MI355X_MICROARCH.md gfx950 correction); "
-                   "Infinity-Cache hits are included; B=256, groups as in bench.py (fwd 6, wgrad/dgrad 2)", "launches": out},
+                   "Infinity-Cache hits are included; B=256, key = '<layer> <op> g<groups per launch>' as launched by bench.py", "launches": out},
           open(sys.argv[1], "w"), indent=1)
 for op, e in out.items(): print(op, round(e["hbm_side_bytes"] / 1e6, 1), "MB")
 PY
