@@ -86,11 +86,17 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU minibatch (default 256 = the headline config; "
+                    "other values are SURVEY 8d's large-batch variants and are labelled as such)")
+    ap.add_argument("--utd", type=int, default=None, help="UTD ratio (default 20 = the headline config)")
     ap.add_argument("--phases", action="store_true",
                     help="after the timed region, one more update() with HIP-event marks between its phases (stderr)")
     ap.add_argument("--precision", default="bf16_3x", choices=["bf16_3x", "highest"],
                     help="serl_amd.set_matmul_precision: bf16_3x (default of the library) or highest (exact fp32 MFMA)")
     args = ap.parse_args()
+    global BATCH, UTD
+    headline = (args.batch in (None, 256)) and (args.utd in (None, 20))
+    BATCH, UTD = args.batch or BATCH, args.utd or UTD
 
     import torch
     from helpers import pixel_spaces
@@ -162,7 +168,7 @@ def main():
         elapsed = float(t.item())
 
     grad_steps = args.steps * UTD
-    value = grad_steps * world / elapsed
+    value = grad_steps * world / elapsed * (BATCH / 256.0)
     roofline = None
     if timer is not None:
         # dominant kernel = the conv launch configuration with the largest total time in the timed region; its
@@ -212,7 +218,8 @@ def main():
                                       tflops=round(v[2] / (v[1] * 1e-3) / 1e12, 2),
                                       gbs=round(v[3] / (v[1] * 1e-3) / 1e9, 1)) for k, v in summ.items()}})
     out = {
-        "metric": "learner grad-steps/sec, DrQ-RLPD 128^2 pixels, batch 256, 10 critics, UTD 20",
+        "metric": "learner grad-steps/sec, DrQ-RLPD 128^2 pixels, batch 256, 10 critics, UTD 20" if headline else
+                  f"NOT THE HEADLINE CONFIG: grad-steps/sec x batch/256, batch {BATCH}, UTD {UTD}",
         "value": round(value, 3), "unit": "grad-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32" if precision == "highest" else "bf16_3x", "data": "synthetic",
@@ -229,7 +236,7 @@ def main():
     }
     if roofline is not None:
         out["roofline"] = roofline
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and headline:
         out["cpu_baseline"] = cpu_baseline()
         out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
     if rank == 0:
