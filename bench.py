@@ -110,12 +110,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal of the N > 1 path on a one-GPU box: SERL_AMD_BENCH_REHEARSAL=1 -> every rank on cuda:0, gloo backend
+    rehearsal = os.environ.get("SERL_AMD_BENCH_REHEARSAL", "0") != "0"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as td
         from serl_amd.dist import DataParallel
-        td.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            td.init_process_group("gloo")
+        else:
+            td.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         dist = DataParallel()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 

@@ -364,6 +364,62 @@ def sac_update(state, cfg, batch, utd_ratio, dtype=torch.float32, collect=None):
     return new, {**actor_info, **critic_info, **temp_info}
 
 
+# --------------------------------------------------------------------------- DDPG
+def ddpg_update_actor(state, cfg, batch, dtype=torch.float32):
+    """serl/agents/ddpg/ddpg_learner.py:117-144: loss = mean(-mean_members q(obs, a)), a ~ pi(.|obs)."""
+    key, rng = prng.split(state["rng"])
+    key2, rng = prng.split(rng)
+    ap = to_torch(state["actor"]["params"], dtype, requires_grad=True)
+    cp = to_torch(state["critic"]["params"], dtype)
+    mean, log_std = actor_dist(ap, batch["observations"], cfg, dtype)
+    a, _ = tanh_normal_sample(mean, log_std, key)
+    q = critic_qs(cp, batch["observations"], a, cfg, dtype).mean(0)             # :137
+    loss = (-q).mean()                                                          # :138
+    leaves = tree_leaves(ap)
+    gl = torch.autograd.grad(loss, [t for _, t in leaves], allow_unused=True)
+    grads = _rebuild(ap, [g if g is not None else torch.zeros_like(t) for g, (_, t) in zip(gl, leaves)])
+    grads_np = to_numpy(grads)
+    new = dict(state)
+    new.update(actor=adam_step(state["actor"], grads_np, cfg["actor_lr"]), rng=rng)
+    return new, dict(actor_loss=float(loss.detach())), dict(grads=grads_np, actions=a.detach().numpy())
+
+
+def ddpg_update(state, cfg, batch, utd_ratio, dtype=torch.float32, collect=None):
+    """serl/agents/ddpg/ddpg_learner.py:202-225.  The critic step (:146-200) is sac_learner.update_critic with one
+    critic, subsample_ensemble(key, params, 1, 1) and no entropy backup: cfg must say num_qs=1, num_min_qs=1,
+    backup_entropy=False."""
+    assert cfg["num_qs"] == 1 and cfg["num_min_qs"] == 1 and not cfg["backup_entropy"]
+    n = len(np.asarray(batch["rewards"]))
+    assert n % utd_ratio == 0                                                   # :216
+    b = n // utd_ratio
+    new = state
+    for i in range(utd_ratio):
+        mini = _slice_batch(batch, b * i, b * (i + 1))
+        new, critic_info, aux = update_critic(new, cfg, mini, dtype)
+        if collect is not None:
+            collect.append(aux)
+    new, actor_info, aux_a = ddpg_update_actor(new, cfg, mini, dtype)
+    if collect is not None:
+        collect.append(aux_a)
+    return new, {**actor_info, **critic_info}
+
+
+def ddpg_sample_actions(state, cfg, obs, dtype=torch.float32):
+    """serl/agents/ddpg/ddpg_learner.py:91-115.  Both `split(self.rng)` calls (:99, :102) start from the SAME rng,
+    so the exploration noise is drawn with the key of the policy sample."""
+    key, rng = prng.split(state["rng"])
+    ap = to_torch(state["actor"]["params"], dtype)
+    with torch.no_grad():
+        mean, log_std = actor_dist(ap, _add_batch(obs), cfg, dtype)
+        a, _ = tanh_normal_sample(mean[0], log_std[0], key)
+    a = a.numpy().astype(np.float32)
+    key, rng = prng.split(state["rng"])                                         # :102 (self.rng again)
+    a = a + prng.normal(key, a.shape).astype(a.dtype) * 0.05                    # :103
+    new = dict(state)
+    new["rng"] = rng
+    return a, new
+
+
 # --------------------------------------------------------------------------- DrQ wrapper
 def unpack(batch):
     """serl/utils/commons.py:7-29."""

@@ -27,7 +27,7 @@ class Agent:
         return new
 
     # ------------------------------------------------------------------ acting
-    def _act(self, observations, key, deterministic):
+    def _act(self, observations, key, deterministic, want_eps=False):
         cfg = self._cfg
         dev = self.actor.store.flat.device
         ws: Workspace = self._shared.setdefault("ws_act", Workspace(dev))
@@ -52,7 +52,9 @@ class Agent:
             zt[:, :cfg.obs_dim].copy_(torch.from_numpy(np.asarray(observations, dtype=np.float32).reshape(1, -1)))
         act = ws.tensor("act", (1, A))
         nn.policy_fwd(cfg, "A", self.actor.store, z, ldz, 1, ws, st, key, 0, 1, act.data_ptr(), A,
-                      deterministic=deterministic, save=False, want_logp=False)
+                      deterministic=deterministic, save=want_eps, want_logp=False)
+        if want_eps:                 # the standard-normal draw behind the sample (DDPGLearner's exploration noise)
+            return act.cpu().numpy()[0], ws.tensor("eps_A", (1, A)).cpu().numpy()[0]
         return act.cpu().numpy()[0]
 
     def eval_actions(self, observations) -> np.ndarray:

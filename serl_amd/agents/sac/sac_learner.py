@@ -57,18 +57,20 @@ class UpdateInfo(Mapping):
     first access (indexing, iteration over items, comparison, dict(info)) copies the 8 floats to the host."""
     KEYS = ("actor_loss", "entropy", "critic_loss", "q", "temperature", "temperature_loss")
 
-    def __init__(self, dev_scalars, global_batch, num_qs):
+    def __init__(self, dev_scalars, global_batch, num_qs, keys=None):
         self._dev, self._bg, self._e, self._host = dev_scalars, global_batch, num_qs, None
+        self._keys = tuple(keys) if keys is not None else self.KEYS
 
     def _materialize(self):
         if self._host is None:
             h = self._dev.cpu().numpy()                      # one small D2H per update call, on first access
             bg, e = self._bg, self._e
-            self._host = {
+            full = {
                 "actor_loss": float(h[2]) / bg, "entropy": float(h[6]),
                 "critic_loss": float(h[0]) / (e * bg), "q": float(h[1]) / (e * bg),
                 "temperature": float(h[4]), "temperature_loss": float(h[5]),
             }
+            self._host = {k: full[k] for k in self._keys}
             self._dev = None
         return self._host
 
@@ -76,16 +78,19 @@ class UpdateInfo(Mapping):
         return self._materialize()[k]
 
     def __iter__(self):
-        return iter(self.KEYS)
+        return iter(self._keys)
 
     def __len__(self):
-        return len(self.KEYS)
+        return len(self._keys)
 
     def __repr__(self):
         return repr(self._materialize())
 
 
 class SACLearner(Agent):
+    _HAS_TEMP = True            # DDPGLearner: no entropy term, no temperature step
+    _INFO_KEYS = UpdateInfo.KEYS
+
     """State-based SAC learner. Fields as in the reference dataclass (sac_learner.py:19-30)."""
 
     # ------------------------------------------------------------------ construction
@@ -104,14 +109,14 @@ class SACLearner(Agent):
 
     @classmethod
     def _build(cls, cfg, seed, actor_lr, critic_lr, temp_lr, discount, tau, num_min_qs, critic_dropout_rate,
-               target_entropy, init_temperature, backup_entropy, device, dist):
+               target_entropy, init_temperature, backup_entropy, device, dist, nkeys=4):
         if critic_dropout_rate:
             raise NotImplementedError("critic dropout is not used by any SERL config and is not implemented")
         dev = _device(device)
         if target_entropy is None:
             target_entropy = -cfg.action_dim / 2                        # sac_learner.py:60-61
         rng = prng.PRNGKey(seed)
-        rng, actor_key, critic_key, temp_key = prng.split(rng, 4)       # :63-64
+        rng, actor_key, critic_key = prng.split(rng, nkeys)[:3]         # :63-64 (4 keys; DDPG: 3, ddpg_learner.py:47)
         al, cl = actor_layout(cfg), critic_layout(cfg)
         actor_store = ParamStore.from_tree(al, init_tree(al, [int(actor_key[0]), int(actor_key[1])]), dev)
         critic_store = ParamStore.from_tree(cl, init_tree(cl, [int(critic_key[0]), int(critic_key[1])]), dev)
@@ -401,12 +406,13 @@ class SACLearner(Agent):
         ops.adam_polyak(actor.store.base, actor.mu.data_ptr(), actor.nu.data_ptr(), agr.base, None,
                         actor.store.flat.numel(), actor.lr, ADAM_B1, ADAM_B2, ADAM_EPS, bc1, bc2, 0.0, 1.0, st)
         # ---- temperature (sac_learner.py:146-158, 236)
-        temp.step += 1
-        bc1, bc2 = bias_corrections(temp.step)
-        ops.temperature_update(temp.buf.data_ptr(), info.data_ptr() + 12, 1.0 / Bg, self.target_entropy, temp.lr,
-                               ADAM_B1, ADAM_B2, ADAM_EPS, bc1, bc2, info.data_ptr() + 16, st)
+        if self._HAS_TEMP:
+            temp.step += 1
+            bc1, bc2 = bias_corrections(temp.step)
+            ops.temperature_update(temp.buf.data_ptr(), info.data_ptr() + 12, 1.0 / Bg, self.target_entropy, temp.lr,
+                                   ADAM_B1, ADAM_B2, ADAM_EPS, bc1, bc2, info.data_ptr() + 16, st)
 
         ops.phase("end")
         new_agent = self.replace(actor=actor, critic=critic, target_critic=target, temp=temp, rng=rng)
         snap = info.clone()         # `info` is workspace memory: the next update() call overwrites it
-        return new_agent, UpdateInfo(snap, Bg, E)
+        return new_agent, UpdateInfo(snap, Bg, E, self._INFO_KEYS)

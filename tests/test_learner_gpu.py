@@ -282,3 +282,33 @@ def test_checkpoint_roundtrip_through_agent(dev, tmp_path):
     assert i1 == i2
     assert torch.equal(a1.critic.store.flat, a2.critic.store.flat) and torch.equal(a1.actor.store.flat, a2.actor.store.flat)
     assert torch.equal(a1.temp.buf, a2.temp.buf) and a1.critic.step == a2.critic.step
+
+
+@pytest.mark.parametrize("layer_norm", [False, True])
+def test_ddpg_learner_matches_oracle(dev, layer_norm, prec):
+    """DDPGLearner (serl/agents/ddpg/ddpg_learner.py): one critic, -mean(q) actor loss, no temperature, info keys
+    actor_loss / critic_loss / q, exploration noise drawn with the policy sample's key."""
+    from oracle import learner as ol
+    from serl_amd.agents import DDPGLearner
+    obs_space, act_space = state_spaces(17, 6)
+    agent = DDPGLearner.create(42, obs_space, act_space, critic_layer_norm=layer_norm)
+    assert agent.num_qs == 1
+    rng = np.random.default_rng(0)
+    B, U = 64, 2
+    for it in range(3):
+        ostate, ocfg = agent_to_oracle(agent)
+        ocfg.update(num_qs=1, num_min_qs=1, backup_entropy=False)
+        batch = make_state_batch(rng, B * U, 17, 6)
+        ostate, oinfo = ol.ddpg_update(ostate, ocfg, batch, U)
+        agent, info = agent.update(batch, U)
+        assert list(info) == ["actor_loss", "critic_loss", "q"]
+        assert_info_close(info, oinfo, rtol=1e-3 if prec == "highest" else 5e-3)
+        assert np.array_equal(agent.rng, ostate["rng"])
+    _check_params(agent, ostate, 3e-4, U)
+    ob = rng.standard_normal(17).astype(np.float32)
+    osync, ocfg = agent_to_oracle(agent)
+    a, agent2 = agent.sample_actions(ob)
+    oa, osync2 = ol.ddpg_sample_actions(osync, ocfg, ob)
+    assert np.allclose(a, oa, atol=5e-4) and np.array_equal(agent2.rng, osync2["rng"])
+    assert np.abs(a).max() > 0 and a.shape == (6,)
+    assert np.allclose(agent.eval_actions(ob), ol.eval_actions(osync, ocfg, ob), atol=5e-4)
