@@ -32,7 +32,10 @@ ACTOR_RUNAHEAD = os.environ.get("SERL_AMD_ACTOR_RUNAHEAD", "1") != "0"
 # (the idle windows are already full with the actor pass), off by default
 CHUNKED_CROP = os.environ.get("SERL_AMD_CHUNKED_CROP", "0") != "0"
 ACTOR_GATE = os.environ.get("SERL_AMD_ACTOR_GATE", "1") != "0"
-DP_OVERLAP = os.environ.get("SERL_AMD_DP_OVERLAP", "1") != "0"   # all-reduce of the head gradients overlapped with the encoder backward
+# all-reduce of the head/trunk gradient leaves issued asynchronously and overlapped with the encoder backward.
+# OFF by default: it cannot be validated on RCCL from a one-GPU box, and under gloo (two ranks on one GPU) the
+# collective after the first asynchronous one never completes at the bench sizes (tools/rehearse_dp.sh).
+DP_OVERLAP = os.environ.get("SERL_AMD_DP_OVERLAP", "0") != "0"   # all-reduce of the head gradients overlapped with the encoder backward
 
 from ..train_state import ADAM_B1, ADAM_B2, ADAM_EPS, TempState, TrainState, bias_corrections
 
