@@ -56,6 +56,9 @@ int serl_split_f32(const float* in, void* out, long long rows, int cols, void* s
 int serl_merge_split(const void* in, float* out, long long rows, int cols, void* stream);
 int serl_convs_prep_weights(int ngroups, const float* const* w, void* const* wf, void* const* wd, int in_u8, int KH,
                             int KW, int C, int F, void* stream);
+/* the same for njobs <= 32 (layer, group) pairs in one launch; argument tables are host arrays of length njobs */
+int serl_convs_prep_weights_multi(int njobs, const float* const* w, void* const* wf, void* const* wd, const int* in_u8,
+                                  const int* KH, const int* KW, const int* C, const int* F, void* stream);
 int serl_convs_fwd(int ngroups, const void* const* x, const void* const* wf, const float* const* bias, void* const* y,
                    int in_u8, int B, int IH, int IW, int C, int KH, int KW, int stride, int F, int relu,
                    void* const* rmask, void* stream);

@@ -17,6 +17,7 @@ c_u = C.c_uint
 c_ll = C.c_longlong
 c_f = C.c_float
 PP = C.POINTER(C.c_void_p)
+PI = C.POINTER(C.c_int)
 
 # name -> argtypes (restype is int status unless listed in _RESTYPE)
 _SIGS = {
@@ -49,6 +50,7 @@ _SIGS = {
     "serl_split_f32": [c_p, c_p, c_ll, c_i, c_p],
     "serl_merge_split": [c_p, c_p, c_ll, c_i, c_p],
     "serl_convs_prep_weights": [c_i, PP, PP, PP, c_i, c_i, c_i, c_i, c_i, c_p],
+    "serl_convs_prep_weights_multi": [c_i, PP, PP, PP, PI, PI, PI, PI, PI, c_p],
     "serl_convs_fwd": [c_i, PP, PP, PP, PP, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, PP, c_p],
     "serl_convs_dgrad": [c_i, PP, PP, PP, PP, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "serl_convs_wgrad": [c_i, PP, PP, PP, PP, c_p, c_ll, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],

@@ -120,7 +120,7 @@ class DrQLearner(SACLearner):
     def _prepare(self, batch, n):
         raise RuntimeError("DrQLearner prepares features inside update()")
 
-    def _features(self, passes, feats, lo, B, ws, st, save_tag=None, trunk_streams=None, fork=None):
+    def _features(self, passes, feats, lo, B, ws, st, save_tag=None, trunk_streams=None, fork=None, prep=True):
         cfg = self._cfg
         ldz = cfg.latent + cfg.action_dim
         img_bytes = cfg.H * cfg.W * 3 * cfg.stack
@@ -128,7 +128,7 @@ class DrQLearner(SACLearner):
         for tag, store, which in passes:
             imgs = [feats["aug"][which][cam].data_ptr() + lo * img_bytes for cam in cfg.cams]
             enc_passes.append((tag, store, imgs))
-        nn.encoder_fwd(cfg, enc_passes, B, ws, st, mask_tag=save_tag)
+        nn.encoder_fwd(cfg, enc_passes, B, ws, st, mask_tag=save_tag, prep=prep)
         if fork is not None:          # the trunks of the passes are independent: side streams wait for the encoders
             fork.record(torch.cuda.current_stream())
             for s_ in trunk_streams.values():

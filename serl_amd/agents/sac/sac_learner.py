@@ -200,7 +200,7 @@ class SACLearner(Agent):
         return dict(obs=_to_dev(batch["observations"], dev, f32).reshape(n, -1),
                     next_obs=_to_dev(batch["next_observations"], dev, f32).reshape(n, -1))
 
-    def _features(self, passes, feats, lo, B, ws, st, save_tag=None, trunk_streams=None, fork=None):
+    def _features(self, passes, feats, lo, B, ws, st, save_tag=None, trunk_streams=None, fork=None, prep=True):
         """passes: list of (tag, store, which) -> fills z_<tag>[:, :latent]. State-based: a strided copy.
         trunk_streams: {tag: torch stream} for passes whose per-pass work may run on a side stream; `fork` is
         the event the side streams wait on (recorded here, after everything they depend on)."""
@@ -293,7 +293,8 @@ class SACLearner(Agent):
                 if chunked_crop and j > 0:
                     crop(j * B, B, sta)
                     cdone[j].record(astream)
-                self._features([("A", actor.store, "next")], feats, j * B, B, ws, sta)
+                # the actor's parameters are constant during the loop: its S-format weight copies are made once
+                self._features([("A", actor.store, "next")], feats, j * B, B, ws, sta, prep=(j == 0))
                 nn.policy_fwd(cfg, "A", actor.store, zA, ldz, B, ws, sta, step_keys[j][0], rank * B, Bg,
                               next_act + 4 * j * B * A, A, want_logp=self.backup_entropy,
                               logp_out=nlogp_all + 4 * j * B)

@@ -391,6 +391,52 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(const PrepArgs a) {
   }
 }
 
+// All layers x groups of an encoder pass in ONE launch (blockIdx.z = job): the four per-layer launches sat between
+// the dependent conv kernels of the critical path.
+#define PREP_MAX_JOBS 32
+struct PrepJobs {
+  const float* w[PREP_MAX_JOBS]; ushort_t* wf[PREP_MAX_JOBS]; ushort_t* wd[PREP_MAX_JOBS];
+  int KH[PREP_MAX_JOBS], KWC[PREP_MAX_JOBS], F[PREP_MAX_JOBS], Kp[PREP_MAX_JOBS], pad32[PREP_MAX_JOBS];
+};
+__global__ __launch_bounds__(256) void prep_weights_multi_kernel(const PrepJobs a) {
+  __shared__ unsigned short th[32][33], tl[32][33];
+  const int j = blockIdx.z;
+  const int Kp = a.Kp[j], F = a.F[j], KWC = a.KWC[j], pad32 = a.pad32[j];
+  const int kp0 = blockIdx.x * 32, f0 = blockIdx.y * 32;
+  if (kp0 >= Kp || f0 >= F) return;                       // block-uniform: the grid covers the largest job
+  const float* w = a.w[j]; ushort_t* wf = a.wf[j]; ushort_t* wd = a.wd[j];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int kp = kp0 + ty + 8 * i, f = f0 + tx;
+    int k = kp;
+    bool valid = kp < Kp && f < F;
+    if (pad32) {
+      const int ky = kp >> 5, jj = kp & 31;
+      valid = valid && jj < KWC;
+      k = ky * KWC + jj;
+    }
+    ushort_t h = 0, l = 0;
+    if (valid) {
+      split1(w[(size_t)k * F + f], h, l);
+      if (wd != nullptr) {
+        wd[(size_t)(k * 2) * F + f] = h;
+        wd[(size_t)(k * 2 + 1) * F + f] = l;
+      }
+    }
+    th[ty + 8 * i][tx] = h; tl[ty + 8 * i][tx] = l;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int f = f0 + ty + 8 * i, kp = kp0 + tx;
+    if (f < F && kp < Kp) {
+      wf[(size_t)(f * 2) * Kp + kp] = th[tx][ty + 8 * i];
+      wf[(size_t)(f * 2 + 1) * Kp + kp] = tl[tx][ty + 8 * i];
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------ host API
 // Tiles (measured per layer, tools/bench_conv.py): one LDS stage (two barriers per K-step, half the LDS, more blocks
 // per CU) wins everywhere except the 128-wide weight gradients; a 64-deep K slab (full 128-byte lines per row chunk)
@@ -456,6 +502,27 @@ extern "C" int serl_convs_prep_weights(int ngroups, const float* const* w, void*
   }
   hipLaunchKernelGGL(prep_weights_kernel, dim3(cdiv(a.Kp, 32), cdiv(F, 32), ngroups), dim3(256), 0, (hipStream_t)stream, a);
   SERL_CHECK_LAUNCH("convs_prep_weights");
+  return SERL_OK;
+}
+
+extern "C" int serl_convs_prep_weights_multi(int njobs, const float* const* w, void* const* wf, void* const* wd,
+                                             const int* in_u8, const int* KH, const int* KW, const int* C, const int* F,
+                                             void* stream) {
+  SERL_CHECK_ARG(njobs >= 1 && njobs <= PREP_MAX_JOBS, "convs_prep_weights_multi: njobs must be in [1,%d]", PREP_MAX_JOBS);
+  SERL_CHECK_ARG(w && wf && in_u8 && KH && KW && C && F, "convs_prep_weights_multi: null argument table");
+  PrepJobs a;
+  int gx = 0, gy = 0;
+  for (int i = 0; i < njobs; ++i) {
+    SERL_CHECK_ARG(KH[i] > 0 && KW[i] > 0 && C[i] > 0 && F[i] > 0 && F[i] % 8 == 0, "convs_prep_weights_multi: F must be a multiple of 8");
+    SERL_CHECK_ARG(in_u8[i] ? KW[i] * C[i] <= 32 : C[i] % 8 == 0,
+                   "convs_prep_weights_multi: need C %% 8 == 0 (or KW*C <= 32 for uint8 input)");
+    SERL_CHECK_ARG(w[i] && wf[i], "convs_prep_weights_multi: null pointer");
+    a.w[i] = w[i]; a.wf[i] = (ushort_t*)wf[i]; a.wd[i] = wd ? (ushort_t*)wd[i] : nullptr;
+    a.KH[i] = KH[i]; a.KWC[i] = KW[i] * C[i]; a.F[i] = F[i]; a.Kp[i] = s_kp(in_u8[i], KH[i], KW[i], C[i]); a.pad32[i] = in_u8[i];
+    gx = a.Kp[i] > gx ? a.Kp[i] : gx; gy = F[i] > gy ? F[i] : gy;
+  }
+  hipLaunchKernelGGL(prep_weights_multi_kernel, dim3(cdiv(gx, 32), cdiv(gy, 32), njobs), dim3(256), 0, (hipStream_t)stream, a);
+  SERL_CHECK_LAUNCH("convs_prep_weights_multi");
   return SERL_OK;
 }
 

@@ -106,11 +106,13 @@ def _rmask_ptr(ws, li, tag, ci, B, L):
     return ws.ptr(f"rmask{li}_{tag}_{ci}", ((B * L.OH * L.OW * L.F // 8 + 3) // 4,))
 
 
-def encoder_fwd(cfg: NetConfig, passes, B, ws: Workspace, st, mask_tag=None):
+def encoder_fwd(cfg: NetConfig, passes, B, ws: Workspace, st, mask_tag=None, prep=True):
     """passes: list of (tag, ParamStore, [u8 image ptr per camera in cfg.cams order]).
     All passes x cameras run as groups of one launch per conv layer. Writes ws['enc_<tag>'] (B, enc_dim).
     S-format stack: the pass `mask_tag` (the one encoder_bwd will be called for) also writes the ReLU byte masks of
-    its hidden activations, which encoder_bwd(use_masks=True) reads instead of the activations' hi planes."""
+    its hidden activations, which encoder_bwd(use_masks=True) reads instead of the activations' hi planes.
+    prep=False: the S-format weight copies wf/wd of these passes are still valid (parameters unchanged since the
+    last call with prep=True), skip re-laying them out."""
     layers = cfg.conv_layers()
     nl, ncam = len(layers), len(cfg.cams)
     split = split_conv_stack(cfg)
@@ -118,19 +120,29 @@ def encoder_fwd(cfg: NetConfig, passes, B, ws: Workspace, st, mask_tag=None):
     for g0 in range(0, len(groups), 8):
         chunk = groups[g0:g0 + 8]
         xs = [g[3] for g in chunk]
+        wf_all = []
+        if split:
+            jobs = []
+            for li, L in enumerate(layers):
+                nwf = ops.convs_weight_bytes(li == 0, L.K, L.K, L.C, L.F) // 4
+                wfs = [ws.ptr(f"wf{li}_{g[0]}_{g[2]}", (nwf,)) for g in chunk]
+                wds = [ws.ptr(f"wd{li}_{g[0]}_{g[2]}", (L.K * L.K * L.C * L.F,)) if li > 0 else 0 for g in chunk]
+                wf_all.append(wfs)
+                for g, wf, wd in zip(chunk, wfs, wds):
+                    jobs.append((g[1].ptr("image_encoder", f"Conv_{g[2] * nl + li}", "kernel"), wf, wd, li == 0,
+                                 L.K, L.K, L.C, L.F))
+            if prep:      # every (layer, group) in one launch, ahead of the dependent chain of conv kernels
+                for j0 in range(0, len(jobs), 32):
+                    ops.convs_prep_weights_multi(jobs[j0:j0 + 32], st)
         for li, L in enumerate(layers):
             wsp = [g[1].ptr("image_encoder", f"Conv_{g[2] * nl + li}", "kernel") for g in chunk]
             bsp = [g[1].ptr("image_encoder", f"Conv_{g[2] * nl + li}", "bias") for g in chunk]
             ys = [ws.ptr(f"act{li}_{g[0]}_{g[2]}", (B, L.OH, L.OW, L.F)) for g in chunk]
             if split:
-                nwf = ops.convs_weight_bytes(li == 0, L.K, L.K, L.C, L.F) // 4
-                wfs = [ws.ptr(f"wf{li}_{g[0]}_{g[2]}", (nwf,)) for g in chunk]
-                wds = [ws.ptr(f"wd{li}_{g[0]}_{g[2]}", (L.K * L.K * L.C * L.F,)) for g in chunk] if li > 0 else None
-                ops.convs_prep_weights(wsp, wfs, wds, li == 0, L.K, L.K, L.C, L.F, st)
                 rm = None
                 if mask_tag is not None and li < nl - 1 and any(g[0] == mask_tag for g in chunk):
                     rm = [_rmask_ptr(ws, li, g[0], g[2], B, L) if g[0] == mask_tag else 0 for g in chunk]
-                ops.convs_fwd(xs, wfs, bsp, ys, li == 0, B, L.IH, L.IW, L.C, L.K, L.K, L.S, L.F, True, st, rmasks=rm)
+                ops.convs_fwd(xs, wf_all[li], bsp, ys, li == 0, B, L.IH, L.IW, L.C, L.K, L.K, L.S, L.F, True, st, rmasks=rm)
             else:
                 ops.conv2d_fwd(xs, wsp, bsp, ys, li == 0, B, L.IH, L.IW, L.C, L.K, L.K, L.S, L.F, True, st)
             xs = ys

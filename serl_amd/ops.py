@@ -137,6 +137,15 @@ def convs_prep_weights(ws, wfs, wds, in_u8, KH, KW, C, F, stream):
     call("serl_convs_prep_weights", n, pw, pf, pd, int(in_u8), KH, KW, C, F, stream)
 
 
+def convs_prep_weights_multi(jobs, stream):
+    """jobs: list of (w, wf, wd or 0, in_u8, KH, KW, C, F) -- every (layer, group) of an encoder pass in one launch."""
+    import ctypes
+    n = len(jobs)
+    pw, kw_ = ptr_table([j[0] for j in jobs]); pf, kf = ptr_table([j[1] for j in jobs]); pd, kd = ptr_table([j[2] for j in jobs])
+    cols = [(ctypes.c_int * n)(*[int(j[c]) for j in jobs]) for c in range(3, 8)]
+    call("serl_convs_prep_weights_multi", n, pw, pf, pd, *cols, stream)
+
+
 def convs_fwd(xs, wfs, bs, ys, in_u8, B, IH, IW, C, KH, KW, stride, F, relu, stream, rmasks=None):
     n = len(xs)
     px, kx = ptr_table(xs); pw, kw = ptr_table(wfs); pb, kb = ptr_table(bs); py, ky = ptr_table(ys)

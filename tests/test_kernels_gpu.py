@@ -581,3 +581,28 @@ def test_error_channel(dev):
         ops.fill(0, 1.0, 10, 0)
     with pytest.raises(ValueError):
         ops.conv2d_fwd([1] * 9, [1] * 9, [1] * 9, [1] * 9, False, 1, 8, 8, 3, 3, 3, 1, 4, True, 0)
+
+
+def test_prep_weights_multi_equals_single(dev):
+    """serl_convs_prep_weights_multi (all layers x groups of a pass in one launch) writes the same wf / wd bits as
+    one serl_convs_prep_weights call per layer."""
+    ops = _ops()
+    st = ops.current_stream()
+    rng = np.random.default_rng(3)
+    layers = [(True, 3, 9, 32), (False, 3, 32, 64), (False, 3, 64, 40)]          # (in_u8, K, C, F)
+    jobs, singles = [], []
+    for u8, K, C, F in layers:
+        for g in range(2):
+            w = dv((rng.standard_normal((K, K, C, F)) * 0.1).astype(np.float32), dev)
+            nwf = ops.convs_weight_bytes(u8, K, K, C, F) // 2
+            wf = [torch.full((nwf,), -1, dtype=torch.int16, device=dev) for _ in range(2)]
+            wd = [torch.full((K * K * C * F * 2,), -1, dtype=torch.int16, device=dev) for _ in range(2)]
+            jobs.append((w.data_ptr(), wf[0].data_ptr(), 0 if u8 else wd[0].data_ptr(), u8, K, K, C, F))
+            ops.convs_prep_weights([w.data_ptr()], [wf[1].data_ptr()], None if u8 else [wd[1].data_ptr()], u8, K, K, C, F, st)
+            singles.append((w, wf, wd, u8))
+    ops.convs_prep_weights_multi(jobs, st)
+    torch.cuda.synchronize()
+    for w, wf, wd, u8 in singles:
+        assert torch.equal(wf[0], wf[1])
+        if not u8:
+            assert torch.equal(wd[0], wd[1])
