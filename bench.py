@@ -157,6 +157,14 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     ops.TIMER = None
+    # end to end: the same loop with the host-side index draw, rejection resampling and H2D of the small leaves inside
+    # it (the iterator samples batch i+1 while the GPU runs update i: update() does not block the host)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        agent, info = agent.update(next(it), UTD, pixel_keys=KEYS)
+    barrier()
+    e2e = time.perf_counter() - t0
     if args.phases and rank == 0:
         ops.PHASES = marks = []
         agent.update(batches[-1], UTD, pixel_keys=KEYS)
@@ -239,6 +247,9 @@ def main():
         "matmul_precision": precision,
         "model_tflops": round(value * FLOP_PER_GRAD_STEP / 1e12, 2),
         "host_index_sampling_ms_per_update": round(sample_ms, 2),
+        "end_to_end_value": round(args.steps * UTD * world / e2e * (BATCH / 256.0), 3),
+        "end_to_end_note": "same steps with buffer.sample (index draw + rejection + H2D of state/action leaves) inside "
+                           "the loop; frames stay in HBM",
         "last_info": {k: round(float(v), 5) for k, v in info.items()},
     }
     if roofline is not None:
