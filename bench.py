@@ -154,6 +154,7 @@ def main():
     t0 = time.perf_counter()
     for b in batches[args.warmup:]:
         agent, info = agent.update(b, UTD, pixel_keys=KEYS)
+    host_enqueue = time.perf_counter() - t0           # update() does not wait for the GPU: this is pure launch time
     barrier()
     elapsed = time.perf_counter() - t0
     ops.TIMER = None
@@ -247,6 +248,7 @@ def main():
         "matmul_precision": precision,
         "model_tflops": round(value * FLOP_PER_GRAD_STEP / 1e12, 2),
         "host_index_sampling_ms_per_update": round(sample_ms, 2),
+        "host_enqueue_ms_per_step": round(host_enqueue / args.steps * 1e3, 2),
         "end_to_end_value": round(args.steps * UTD * world / e2e * (BATCH / 256.0), 3),
         "end_to_end_note": "same steps with buffer.sample (index draw + rejection + H2D of state/action leaves) inside "
                            "the loop; frames stay in HBM",
