@@ -312,3 +312,54 @@ def test_ddpg_learner_matches_oracle(dev, layer_norm, prec):
     assert np.allclose(a, oa, atol=5e-4) and np.array_equal(agent2.rng, osync2["rng"])
     assert np.abs(a).max() > 0 and a.shape == (6,)
     assert np.allclose(agent.eval_actions(ob), ol.eval_actions(osync, ocfg, ob), atol=5e-4)
+
+
+@pytest.mark.parametrize("repeat", [0, 1, 2])
+def test_learner_thread_and_acting_thread(dev, repeat):
+    """The reference's threading pattern (serl_examples/*: learner_thread + main loop): one thread calls update()
+    while another keeps acting with an OLDER agent copy.  Agents are immutable, so the acting thread's actions must
+    equal those of the same calls made with nothing else running, and the learner's result must equal a solo run."""
+    import threading
+    from serl_amd.agents import DrQLearner
+    keys = ("wrist_1", "wrist_2")
+    H = W = 32; S = 1
+    obs_space, act_space = pixel_spaces(keys, H, W, S, 19, 7)
+    kw = dict(pixel_keys=keys, num_qs=4, num_min_qs=2, critic_layer_norm=True, backup_entropy=False)
+    rng = np.random.default_rng(0)
+    agent0 = DrQLearner.create(3, obs_space, act_space, **kw)
+    batches = [make_pixel_batch(rng, 16, keys, H, W, S, 19, 7, packed=True) for _ in range(4)]
+    obs = [dict({k: rng.integers(0, 256, size=(H, W, 3, S), dtype=np.uint8) for k in keys},
+                state=rng.standard_normal(19).astype(np.float32)) for _ in range(40)]
+
+    def learn(agent):
+        for b in batches:
+            agent, info = agent.update(b, 4, pixel_keys=keys)
+        return agent, dict(info)
+
+    def act(agent):
+        out = []
+        for ob in obs:
+            a, agent = agent.sample_actions(ob)
+            out.append(a)
+        return np.stack(out)
+
+    solo_agent, solo_info = learn(agent0)
+    solo_actions = act(agent0)
+    res, errs = {}, []
+
+    def run(name, fn):
+        try:
+            torch.cuda.set_device(0)
+            res[name] = fn(agent0)
+        except Exception as e:      # noqa: BLE001
+            errs.append((name, repr(e)))
+    ts = [threading.Thread(target=run, args=("learn", learn)), threading.Thread(target=run, args=("act", act))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=120)
+    assert not errs, errs
+    assert np.array_equal(res["act"], solo_actions)
+    assert res["learn"][1] == solo_info
+    assert torch.equal(res["learn"][0].critic.store.flat, solo_agent.critic.store.flat)
+    assert torch.equal(res["learn"][0].actor.store.flat, solo_agent.actor.store.flat)
