@@ -74,11 +74,7 @@ __device__ __forceinline__ void igemm_epilogue(const P& p, const typename P::Ctx
       const int m = m0 + wm * (TM * 32) + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
 #pragma unroll
       for (int j = 0; j < TN; ++j)
-#ifdef SG_NO_STORE
-        if (m < M && ncol[j] < N && acc[i][j][q] == 12345.678f) p.store(ctx, orow[q], ocol[j], ncol[j], split, acc[i][j][q], aux[q][j]);
-#else
         if (m < M && ncol[j] < N) p.store(ctx, orow[q], ocol[j], ncol[j], split, acc[i][j][q], aux[q][j]);
-#endif
     }
   }
 }

@@ -139,14 +139,14 @@ __global__ __launch_bounds__(T::NT, SG_MIN_WAVES) void sgemm_kernel(const P p) {
   const bool a_on = (NA * A_STEP == A_EXT) || (a_s < A_EXT);
   const bool b_on = (NB * B_STEP == B_EXT) || (b_s < B_EXT);
 
-  // two register sets: the loads of K-step t+2 are issued while step t is multiplied and step t+1 (loaded one
-  // iteration earlier) is written to LDS -- one step of lookahead left every K-step waiting a full HBM round trip.
+  // register sets of the prefetch: SG_DEPTH 1 (default) uses set 0 only (loads of step t+1 issued before the MFMAs
+  // of step t); SG_DEPTH 2 alternates two sets (loads of t+2 in flight while t is multiplied): measured 2 % slower.
   u32x4_t ahi[2][NA], alo[2][ALO ? NA : 1], bhi[2][NB], blo[2][BLO ? NB : 1];
   unsigned long long a8[2][AU8 ? NA : 1];
   int a8sh[2][AU8 ? NA : 1];
   auto gload = [&](auto set_tag, int k0) {
     constexpr int S_ = decltype(set_tag)::value;
-#ifdef SG_NO_LOAD   // experiment: only the first two K-steps are loaded
+#ifdef SG_NO_LOAD   // ablation build: only the first two K-steps are loaded
     if (k0 >= kbeg + 2 * BK) return;
 #endif
     if (a_on) {
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(T::NT, SG_MIN_WAVES) void sgemm_kernel(const P p) {
       for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
   auto mma = [&](int cur) {
-#ifdef SG_NO_MMA
+#ifdef SG_NO_MMA    // ablation build: no LDS reads / MFMAs
     return;
 #endif
     const unsigned char* Ah = As + cur * A_BUF;
