@@ -120,7 +120,8 @@ class DrQLearner(SACLearner):
     def _prepare(self, batch, n):
         raise RuntimeError("DrQLearner prepares features inside update()")
 
-    def _features(self, passes, feats, lo, B, ws, st, save_tag=None, trunk_streams=None, fork=None, prep=True):
+    def _features(self, passes, feats, lo, B, ws, st, save_tag=None, trunk_streams=None, fork=None, prep=True,
+                  z_ptrs=None):
         cfg = self._cfg
         ldz = cfg.latent + cfg.action_dim
         img_bytes = cfg.H * cfg.W * 3 * cfg.stack
@@ -136,8 +137,9 @@ class DrQLearner(SACLearner):
         for tag, store, which in passes:
             state = feats["next_state" if which == "next" else "state"]
             st_ = trunk_streams[tag].cuda_stream if trunk_streams and tag in trunk_streams else st
-            nn.trunk_fwd(cfg, tag, store, state.data_ptr() + 4 * lo * cfg.state_dim, ws.ptr(f"z{tag}", (B, ldz)), ldz,
-                         B, ws, st_, save=(tag == save_tag))
+            z = z_ptrs[tag] if z_ptrs and tag in z_ptrs else ws.ptr(f"z{tag}", (B, ldz))
+            nn.trunk_fwd(cfg, tag, store, state.data_ptr() + 4 * lo * cfg.state_dim, z, ldz, B, ws, st_,
+                         save=(tag == save_tag))
 
     def _features_bwd(self, tag, store, grads, feats, lo, B, ws, st, dz_ptr, lddz, need_encoder, gside=None,
                       on_head_grads=None):

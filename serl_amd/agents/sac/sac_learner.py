@@ -200,8 +200,9 @@ class SACLearner(Agent):
         return dict(obs=_to_dev(batch["observations"], dev, f32).reshape(n, -1),
                     next_obs=_to_dev(batch["next_observations"], dev, f32).reshape(n, -1))
 
-    def _features(self, passes, feats, lo, B, ws, st, save_tag=None, trunk_streams=None, fork=None, prep=True):
-        """passes: list of (tag, store, which) -> fills z_<tag>[:, :latent]. State-based: a strided copy.
+    def _features(self, passes, feats, lo, B, ws, st, save_tag=None, trunk_streams=None, fork=None, prep=True,
+                  z_ptrs=None):
+        """passes: list of (tag, store, which) -> fills z_<tag>[:, :latent] (or z_ptrs[tag]). State-based: a strided copy.
         trunk_streams: {tag: torch stream} for passes whose per-pass work may run on a side stream; `fork` is
         the event the side streams wait on (recorded here, after everything they depend on)."""
         if fork is not None:
@@ -213,8 +214,8 @@ class SACLearner(Agent):
         for tag, _store, which in passes:
             src = feats["next_obs" if which == "next" else "obs"]
             st_ = trunk_streams[tag].cuda_stream if trunk_streams and tag in trunk_streams else st
-            ops.copy2d(ws.ptr(f"z{tag}", (B, ldz)), ldz, src.data_ptr() + 4 * lo * cfg.obs_dim, cfg.obs_dim, B,
-                       cfg.obs_dim, st_)
+            z = z_ptrs[tag] if z_ptrs and tag in z_ptrs else ws.ptr(f"z{tag}", (B, ldz))
+            ops.copy2d(z, ldz, src.data_ptr() + 4 * lo * cfg.obs_dim, cfg.obs_dim, B, cfg.obs_dim, st_)
 
     def _features_bwd(self, tag, store, grads, feats, lo, B, ws, st, dz_ptr, lddz, need_encoder, gside=None,
                       on_head_grads=None):
@@ -267,7 +268,7 @@ class SACLearner(Agent):
         ss = self._side_streams()
         main = torch.cuda.current_stream()
         s0, s1 = ss["s"]
-        next_act = nlogp_all = None
+        zT_all = nlogp_all = None
         # pixel learners: fused gather + crop of the minibatch rows (feats["crop"]).  With the run-ahead stream only the
         # first minibatch is augmented up front; minibatch j+1 is augmented on that stream during critic step j.
         crop = feats.get("crop")
@@ -285,7 +286,9 @@ class SACLearner(Agent):
                 cdone.append(torch.cuda.Event())
             ss["astart"].record(main)
             astream.wait_event(ss["astart"])
-            next_act = ws.ptr("next_act_all", (utd_ratio, B, A))
+            # per-step input buffers of the target ensemble: the run-ahead pass writes the next action straight into
+            # the action columns of step j's buffer, the target trunk of step j fills the latent columns later
+            zT_all = ws.ptr("zT_all", (utd_ratio, B, ldz))
             nlogp_all = ws.ptr("nlogp_all", (utd_ratio, B))
             sta = astream.cuda_stream
 
@@ -296,7 +299,7 @@ class SACLearner(Agent):
                 # the actor's parameters are constant during the loop: its S-format weight copies are made once
                 self._features([("A", actor.store, "next")], feats, j * B, B, ws, sta, prep=(j == 0))
                 nn.policy_fwd(cfg, "A", actor.store, zA, ldz, B, ws, sta, step_keys[j][0], rank * B, Bg,
-                              next_act + 4 * j * B * A, A, want_logp=self.backup_entropy,
+                              zT_all + 4 * (j * B * ldz + cfg.latent), ldz, want_logp=self.backup_entropy,
                               logp_out=nlogp_all + 4 * j * B)
                 adone[j].record(astream)
             # the host interleaves the two streams' launches (pass j+1 is enqueued inside critic step j): enqueued all
@@ -316,8 +319,10 @@ class SACLearner(Agent):
                 # target chain on the main stream, critic chain on a side stream, next action from the actor stream
                 if chunked_crop and i > 0:
                     main.wait_event(ss["cdone"][i])
+                zT = zT_all + 4 * i * B * ldz
                 self._features([("T", target.store, "next"), ("C", critic.store, "obs")],
-                               feats, lo, B, ws, st, save_tag="C", trunk_streams={"C": s1}, fork=ss["fork"])
+                               feats, lo, B, ws, st, save_tag="C", trunk_streams={"C": s1}, fork=ss["fork"],
+                               z_ptrs={"T": zT})
                 ops.phase("features_fwd")
                 if i + 1 < utd_ratio:
                     if ACTOR_GATE:       # start pass i+1 when the main stream leaves its (HBM-bound) encoder forward
@@ -325,7 +330,6 @@ class SACLearner(Agent):
                         astream.wait_event(ss["agate"])
                     enqueue_actor(i + 1)
                 main.wait_event(ss["adone"][i])
-                ops.copy2d(zT + 4 * cfg.latent, ldz, next_act + 4 * i * B * A, A, B, A, st)
                 nlogp = nlogp_all + 4 * i * B if self.backup_entropy else None
             else:
                 # encoders of the three passes in grouped launches on the main stream, then three concurrent chains:
