@@ -94,6 +94,13 @@ int serl_gemm(const float* a, const float* b, float* c, const float* bias, int n
 int serl_ln_act_fwd(const float* pre, int nslab, long long pre_slab_stride, int ldpre, const float* bias,
                     const float* gamma, const float* beta, long long param_group_stride, float* y, int ldy,
                     float* xhat, float* rstd, int R, int N, int rows_per_group, int use_ln, int act, void* stream);
+/* ... followed by the Dense(1) head of StateActionValue (serl/networks/state_action_value.py:17-19) on the activated
+ * row: q[row] = y[row,:] . head_w[e,:] + head_b[e] (= serl_ln_act_fwd + serl_rowdot in one launch) */
+int serl_ln_act_head_fwd(const float* pre, int nslab, long long pre_slab_stride, int ldpre, const float* bias,
+                         const float* gamma, const float* beta, long long param_group_stride, float* y, int ldy,
+                         float* xhat, float* rstd, int R, int N, int rows_per_group, int use_ln, int act,
+                         const float* head_w, long long head_w_group_stride, const float* head_b,
+                         long long head_b_group_stride, float* q, void* stream);
 int serl_ln_act_bwd(const float* dy, int lddy, const float* dq, const float* w_head, long long w_group_stride,
                     const float* y, int ldy, const float* xhat, const float* rstd, const float* gamma,
                     long long param_group_stride, float* dz, float* g, int R, int N, int rows_per_group, int use_ln,

@@ -33,6 +33,8 @@ _SIGS = {
                   c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll, c_ll,
                   c_i, c_ll, c_i, c_i, c_i, c_i, c_p],
     "serl_ln_act_fwd": [c_p, c_i, c_ll, c_i, c_p, c_p, c_p, c_ll, c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
+    "serl_ln_act_head_fwd": [c_p, c_i, c_ll, c_i, c_p, c_p, c_p, c_ll, c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i,
+                             c_p, c_ll, c_p, c_ll, c_p, c_p],
     "serl_ln_act_bwd": [c_p, c_i, c_p, c_p, c_ll, c_p, c_i, c_p, c_p, c_p, c_ll, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
     "serl_colsum": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_ll, c_p],
     "serl_rowdot": [c_p, c_p, c_ll, c_p, c_ll, c_p, c_i, c_i, c_i, c_p],

@@ -23,6 +23,8 @@ struct LnFwdArgs {
   const float* bias; const float* gamma; const float* beta; long long pgs;  // per-group stride of params
   float* y; int ldy; float* xhat; float* rstd;
   int R, N, rows_per_group, use_ln, act;
+  // optional Dense(1) head on the activated row (state_action_value.py:17-19): q[row] = y[row,:] . hw[e,:] + hb[e]
+  const float* hw; long long hw_gs; const float* hb; long long hb_gs; float* q;
 };
 __global__ __launch_bounds__(256) void ln_act_fwd_kernel(const LnFwdArgs a) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -56,6 +58,8 @@ __global__ __launch_bounds__(256) void ln_act_fwd_kernel(const LnFwdArgs a) {
   }
   const float* gamma = a.use_ln ? a.gamma + e * a.pgs : nullptr;
   const float* beta = a.use_ln ? a.beta + e * a.pgs : nullptr;
+  const float* hw = a.hw ? a.hw + e * a.hw_gs : nullptr;
+  float dot = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXW; ++i) {
     const int n = lane + 64 * i;
@@ -69,7 +73,12 @@ __global__ __launch_bounds__(256) void ln_act_fwd_kernel(const LnFwdArgs a) {
       if (a.act == ACT_RELU) v = fmaxf(v, 0.f);
       else if (a.act == ACT_TANH) v = tanhf(v);
       a.y[(long long)row * a.ldy + n] = v;
+      if (hw) dot += v * hw[n];                 // same lane/column order as rowdot_kernel: bit-identical sums
     }
+  }
+  if (hw) {
+    dot = wave_sum(dot);
+    if (lane == 0) a.q[row] = dot + a.hb[e * a.hb_gs];
   }
 }
 
@@ -81,9 +90,26 @@ extern "C" int serl_ln_act_fwd(const float* pre, int nslab, long long pre_slab_s
   SERL_CHECK_ARG(!use_ln || (gamma && beta), "ln_act_fwd: LayerNorm needs scale and bias");
   SERL_CHECK_ARG(rows_per_group >= 1 && nslab >= 1, "ln_act_fwd: bad grouping");
   LnFwdArgs a{pre, pre_slab_stride, nslab, ldpre, bias, gamma, beta, param_group_stride, y, ldy, xhat, rstd,
-              R, N, rows_per_group, use_ln, act};
+              R, N, rows_per_group, use_ln, act, nullptr, 0, nullptr, 0, nullptr};
   hipLaunchKernelGGL(ln_act_fwd_kernel, dim3(cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, a);
   SERL_CHECK_LAUNCH("ln_act_fwd");
+  return SERL_OK;
+}
+
+// the same with the Dense(1) Q head of the ensemble fused behind the activation (one launch less per ensemble pass)
+extern "C" int serl_ln_act_head_fwd(const float* pre, int nslab, long long pre_slab_stride, int ldpre, const float* bias,
+                                    const float* gamma, const float* beta, long long param_group_stride, float* y,
+                                    int ldy, float* xhat, float* rstd, int R, int N, int rows_per_group, int use_ln,
+                                    int act, const float* head_w, long long head_w_group_stride, const float* head_b,
+                                    long long head_b_group_stride, float* q, void* stream) {
+  SERL_CHECK_ARG(pre && y && R >= 1 && N >= 1 && N <= 64 * MAXW, "ln_act_head_fwd: bad args (N must be <= %d)", 64 * MAXW);
+  SERL_CHECK_ARG(!use_ln || (gamma && beta), "ln_act_head_fwd: LayerNorm needs scale and bias");
+  SERL_CHECK_ARG(rows_per_group >= 1 && nslab >= 1, "ln_act_head_fwd: bad grouping");
+  SERL_CHECK_ARG(head_w && head_b && q, "ln_act_head_fwd: head kernel, bias and output are required");
+  LnFwdArgs a{pre, pre_slab_stride, nslab, ldpre, bias, gamma, beta, param_group_stride, y, ldy, xhat, rstd,
+              R, N, rows_per_group, use_ln, act, head_w, head_w_group_stride, head_b, head_b_group_stride, q};
+  hipLaunchKernelGGL(ln_act_fwd_kernel, dim3(cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, a);
+  SERL_CHECK_LAUNCH("ln_act_head_fwd");
   return SERL_OK;
 }
 

@@ -265,6 +265,11 @@ def ensemble_fwd(cfg: NetConfig, tag, store, m0, mstride, E, inp_ptr, ld_inp, B,
     din = cfg.latent + cfg.action_dim
     ln = cfg.critic_layer_norm
     a_ptr, a_zs, a_ms = inp_ptr, 0, ld_inp
+    nl = len(cfg.hidden_dims)
+    q = ws.ptr(f"q_{tag}", (E, B))
+    hl = cfg.hidden_dims[-1]
+    head = (store.ptr(*pre, "Dense_0", "kernel") + 4 * m0 * hl, mstride * hl,
+            store.ptr(*pre, "Dense_0", "bias") + 4 * m0, mstride, q)
     for i, h in enumerate(cfg.hidden_dims):
         W = store.ptr(*pre, "MLP_0", f"Dense_{i}", "kernel") + 4 * m0 * din * h
         bias = store.ptr(*pre, "MLP_0", f"Dense_{i}", "bias") + 4 * m0 * h
@@ -273,17 +278,18 @@ def ensemble_fwd(cfg: NetConfig, tag, store, m0, mstride, E, inp_ptr, ld_inp, B,
             pbuf = ws.ptr(f"epre{i}_{tag}", (E, B, h))   # per tag: the shape differs between passes (E)
             ops.gemm(a_ptr, W, pbuf, None, E, B, h, din, a_zs=a_zs, a_ms=a_ms, a_ks=1, b_zs=mstride * din * h,
                      b_ks=h, b_ns=1, c_zs=B * h, c_ms=h, stream=st)
+            # the last hidden layer's launch also applies the Dense(1) Q head (state_action_value.py:17-19)
             ops.ln_act_fwd(pbuf, 1, 0, h, bias, store.ptr(*pre, "MLP_0", f"LayerNorm_{i}", "scale") + 4 * m0 * h,
                            store.ptr(*pre, "MLP_0", f"LayerNorm_{i}", "bias") + 4 * m0 * h, mstride * h, hbuf, h,
                            ws.ptr(f"exh{i}_{tag}", (E, B, h)) if save else None,
-                           ws.ptr(f"ers{i}_{tag}", (E * B,)) if save else None, E * B, h, B, True, RELU, st)
+                           ws.ptr(f"ers{i}_{tag}", (E * B,)) if save else None, E * B, h, B, True, RELU, st,
+                           head=head if i == nl - 1 else None)
         else:
             ops.gemm(a_ptr, W, hbuf, bias, E, B, h, din, a_zs=a_zs, a_ms=a_ms, a_ks=1, b_zs=mstride * din * h,
                      b_ks=h, b_ns=1, c_zs=B * h, c_ms=h, bias_zs=mstride * h, relu=True, stream=st)
         a_ptr, a_zs, a_ms, din = hbuf, B * h, h, h
-    q = ws.ptr(f"q_{tag}", (E, B))
-    ops.rowdot(a_ptr, store.ptr(*pre, "Dense_0", "kernel") + 4 * m0 * din, mstride * din,
-               store.ptr(*pre, "Dense_0", "bias") + 4 * m0, mstride, q, E * B, din, B, st)
+    if not ln:
+        ops.rowdot(a_ptr, head[0], head[1], head[2], head[3], q, E * B, din, B, st)
     return q
 
 

@@ -196,7 +196,12 @@ def gemm(a, b, c, bias, nbatch, M, N, K, *, a_zs=0, a_ms, a_ks, b_zs=0, b_ks, b_
 
 
 def ln_act_fwd(pre, nslab, pre_ss, ldpre, bias, gamma, beta, pgs, y, ldy, xhat, rstd, R, N, rows_per_group,
-               use_ln, act, stream):
+               use_ln, act, stream, head=None):
+    """head = (w, w_group_stride, b, b_group_stride, q): fuse the Dense(1) head q[row] = y[row,:].w[e,:] + b[e]."""
+    if head is not None:
+        call("serl_ln_act_head_fwd", pre, nslab, pre_ss, ldpre, bias, gamma, beta, pgs, y, ldy, xhat, rstd, R, N,
+             rows_per_group, int(use_ln), act, *head, stream)
+        return
     call("serl_ln_act_fwd", pre, nslab, pre_ss, ldpre, bias, gamma, beta, pgs, y, ldy, xhat, rstd, R, N,
          rows_per_group, int(use_ln), act, stream)
 
