@@ -105,6 +105,13 @@ int serl_ln_act_bwd(const float* dy, int lddy, const float* dq, const float* w_h
                     const float* y, int ldy, const float* xhat, const float* rstd, const float* gamma,
                     long long param_group_stride, float* dz, float* g, int R, int N, int rows_per_group, int use_ln,
                     int act, void* stream);
+/* nseg <= 4 LayerNorm + activation backward problems over the same R rows in one launch, dy = sum of dy_nslab split-K
+ * partials (slab stride in floats): the two trunk branches of PixelMultiplexer (pixel_multiplexer.py:34-43) reading
+ * the critic's input gradient from the slabs of the GEMM that produced it. Argument tables are host arrays. */
+int serl_ln_act_bwd_seg(int nseg, const float* const* dy, const int* lddy, int dy_nslab, long long dy_slab_stride,
+                        const float* const* y, const int* ldy, const float* const* xhat, const float* const* rstd,
+                        const float* const* gamma, float* const* dz, float* const* g, int R, const int* N, int act,
+                        void* stream);
 /* column sums over the batch (bias / LayerNorm / Dense(1) gradients), fixed order */
 int serl_colsum(const float* x0, const float* w, const float* mul, float* out0, const float* x1, float* out1,
                 const float* x2, const float* mul2, float* out2, int ngroups, int rows_per_group, int N, int ldx,

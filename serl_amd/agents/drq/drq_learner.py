@@ -142,13 +142,13 @@ class DrQLearner(SACLearner):
                          save=(tag == save_tag))
 
     def _features_bwd(self, tag, store, grads, feats, lo, B, ws, st, dz_ptr, lddz, need_encoder, gside=None,
-                      on_head_grads=None):
+                      on_head_grads=None, dz_slabs=(1, 0)):
         cfg = self._cfg
         ldz = cfg.latent + cfg.action_dim
         which = "obs"
         state = feats["state"]
         nn.trunk_bwd(cfg, tag, store, grads, state.data_ptr() + 4 * lo * cfg.state_dim, ws.ptr(f"z{tag}", (B, ldz)),
-                     ldz, dz_ptr, lddz, B, ws, st, need_denc=need_encoder, gside=gside)
+                     ldz, dz_ptr, lddz, B, ws, st, need_denc=need_encoder, gside=gside, dz_slabs=dz_slabs)
         if on_head_grads is not None:      # every gradient leaf outside image_encoder/* is enqueued now
             on_head_grads()
         if need_encoder:

@@ -218,7 +218,7 @@ class SACLearner(Agent):
             ops.copy2d(z, ldz, src.data_ptr() + 4 * lo * cfg.obs_dim, cfg.obs_dim, B, cfg.obs_dim, st_)
 
     def _features_bwd(self, tag, store, grads, feats, lo, B, ws, st, dz_ptr, lddz, need_encoder, gside=None,
-                      on_head_grads=None):
+                      on_head_grads=None, dz_slabs=(1, 0)):
         if on_head_grads is not None:      # no trainable feature stage for state inputs: all gradients are enqueued
             on_head_grads()
 
@@ -356,7 +356,11 @@ class SACLearner(Agent):
             if gside is None:
                 gside = self._shared["grad_side"] = nn.GradSide()
             gside.begin()
-            dinp = nn.ensemble_bwd(cfg, "C", critic.store, cgr, dq, zC, ldz, B, ws, st, gside=gside)
+            # pixel learners: the trunk backward sums the split-K slabs of the input gradient on read; state-based:
+            # observations are not trainable, the critic step needs no input gradient at all
+            dslab = nn.ensemble_bwd(cfg, "C", critic.store, cgr, dq, zC, ldz, B, ws, st, gside=gside,
+                                    dinp="slabs" if cfg.pixel else None)
+            dinp, dz_slabs = (dslab[0], dslab[1:]) if dslab is not None else (None, (1, 0))
             ops.phase("ensemble_bwd")
             # data parallel: the head / trunk gradient leaves (everything behind the image_encoder/* prefix of the flat
             # buffer) are complete before the conv backward starts; their all-reduce runs behind the side stream's
@@ -368,7 +372,7 @@ class SACLearner(Agent):
                 if dist is not None and DP_OVERLAP:
                     head_work.append(dist.all_reduce_sum_async(cgr.flat[enc_n:], gside.side))
             self._features_bwd("C", critic.store, cgr, feats, lo, B, ws, st, dinp, ldz, need_encoder=True, gside=gside,
-                               on_head_grads=reduce_heads)
+                               on_head_grads=reduce_heads, dz_slabs=dz_slabs)
             gside.join()
             ops.phase("features_bwd")
             if dist is not None:

@@ -187,6 +187,76 @@ extern "C" int serl_ln_act_bwd(const float* dy, int lddy, const float* dq, const
   return SERL_OK;
 }
 
+// Several act(LN(.)) backward problems over the SAME rows in one launch (blockIdx.y = segment), with dy given as the
+// sum of `nslab` split-K partials: the trunk's two LayerNorm branches read their column ranges of the ensemble's
+// input gradient straight from the split-K slabs of the producing GEMM (one launch instead of slab-sum + 2 x LN bwd).
+#define LN_MAXSEG 4
+struct LnBwdSegArgs {
+  const float* dy[LN_MAXSEG]; int lddy[LN_MAXSEG]; const float* y[LN_MAXSEG]; int ldy[LN_MAXSEG];
+  const float* xhat[LN_MAXSEG]; const float* rstd[LN_MAXSEG]; const float* gamma[LN_MAXSEG];
+  float* dz[LN_MAXSEG]; float* g[LN_MAXSEG]; int N[LN_MAXSEG];
+  int nslab; long long dy_ss; int R, act;
+};
+__global__ __launch_bounds__(256) void ln_act_bwd_seg_kernel(const LnBwdSegArgs a) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= a.R) return;
+  const int sg = blockIdx.y;
+  const int N = a.N[sg];
+  const float* gamma = a.gamma[sg];
+  float gv[MAXW], xh[MAXW];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXW; ++i) {
+    const int n = lane + 64 * i;
+    float g = 0.f, x = 0.f;
+    if (n < N) {
+      const float* src = a.dy[sg] + (long long)row * a.lddy[sg] + n;
+      float d = 0.f;
+#pragma unroll 8
+      for (int k = 0; k < a.nslab; ++k) d += src[k * a.dy_ss];
+      const float yv = a.y[sg][(long long)row * a.ldy[sg] + n];
+      float dact = 1.f;
+      if (a.act == ACT_RELU) dact = yv > 0.f ? 1.f : 0.f;
+      else if (a.act == ACT_TANH) dact = 1.f - yv * yv;
+      g = d * dact;
+      x = a.xhat[sg][(long long)row * N + n];
+      const float dxh = g * gamma[n];
+      s1 += dxh;
+      s2 += dxh * x;
+    }
+    gv[i] = g;
+    xh[i] = x;
+  }
+  const float m1 = wave_sum(s1) / (float)N, m2 = wave_sum(s2) / (float)N, rs = a.rstd[sg][row];
+#pragma unroll
+  for (int i = 0; i < MAXW; ++i) {
+    const int n = lane + 64 * i;
+    if (n < N) {
+      a.g[sg][(long long)row * N + n] = gv[i];
+      a.dz[sg][(long long)row * N + n] = rs * (gv[i] * gamma[n] - m1 - xh[i] * m2);
+    }
+  }
+}
+extern "C" int serl_ln_act_bwd_seg(int nseg, const float* const* dy, const int* lddy, int dy_nslab,
+                                   long long dy_slab_stride, const float* const* y, const int* ldy,
+                                   const float* const* xhat, const float* const* rstd, const float* const* gamma,
+                                   float* const* dz, float* const* g, int R, const int* N, int act, void* stream) {
+  SERL_CHECK_ARG(nseg >= 1 && nseg <= LN_MAXSEG, "ln_act_bwd_seg: nseg must be in [1,%d]", LN_MAXSEG);
+  SERL_CHECK_ARG(dy && lddy && y && ldy && xhat && rstd && gamma && dz && g && N, "ln_act_bwd_seg: null argument table");
+  SERL_CHECK_ARG(R >= 1 && dy_nslab >= 1, "ln_act_bwd_seg: bad sizes");
+  LnBwdSegArgs a;
+  for (int i = 0; i < nseg; ++i) {
+    SERL_CHECK_ARG(dy[i] && y[i] && xhat[i] && rstd[i] && gamma[i] && dz[i] && g[i], "ln_act_bwd_seg: null pointer");
+    SERL_CHECK_ARG(N[i] >= 1 && N[i] <= 64 * MAXW, "ln_act_bwd_seg: N must be in [1,%d]", 64 * MAXW);
+    a.dy[i] = dy[i]; a.lddy[i] = lddy[i]; a.y[i] = y[i]; a.ldy[i] = ldy[i]; a.xhat[i] = xhat[i]; a.rstd[i] = rstd[i];
+    a.gamma[i] = gamma[i]; a.dz[i] = dz[i]; a.g[i] = g[i]; a.N[i] = N[i];
+  }
+  a.nslab = dy_nslab; a.dy_ss = dy_slab_stride; a.R = R; a.act = act;
+  hipLaunchKernelGGL(ln_act_bwd_seg_kernel, dim3(cdiv(R, 4), nseg), dim3(256), 0, (hipStream_t)stream, a);
+  SERL_CHECK_LAUNCH("ln_act_bwd_seg");
+  return SERL_OK;
+}
+
 // ------------------------------------------------------------------ column reductions over the batch
 // out_k[e][n] = sum_{r in group e} term_k[r][n], fixed summation order (reproducible):
 //   k=0: x0[r][n] * (w ? w[r] : 1) * (mul ? mul[r][n] : 1)      k=1: x1[r][n]      k=2: x2[r][n] * mul2[r][n]

@@ -230,17 +230,21 @@ def trunk_fwd(cfg: NetConfig, tag, store, state_ptr, z_ptr, ldz, B, ws: Workspac
 
 
 def trunk_bwd(cfg: NetConfig, tag, store, grads, state_ptr, z_ptr, ldz, dz_ptr, lddz, B, ws: Workspace, st, need_denc,
-              gside: "GradSide | None" = None):
+              gside: "GradSide | None" = None, dz_slabs=(1, 0)):
+    """dz_ptr: gradient w.r.t. z (row stride lddz), given as the sum of dz_slabs = (count, stride in floats) split-K
+    partials.  Both LayerNorm branches are differentiated in one launch."""
     K, Ld, Sd = cfg.enc_dim, cfg.latent_dim, cfg.state_dim
     stw = st            # stream of the parameter-gradient kernels
     dpre0 = ws.ptr("dpre0", (B, TRUNK_DIM)); g0 = ws.ptr("g0", (B, TRUNK_DIM))
     xh0 = ws.ptr(f"xhat0_{tag}", (B, TRUNK_DIM))
-    ops.ln_act_bwd(dz_ptr, lddz, None, None, 0, z_ptr, ldz, xh0, ws.ptr(f"rstd0_{tag}", (B,)),
-                   store.ptr("LayerNorm_0", "scale"), 0, dpre0, g0, B, TRUNK_DIM, B, True, TANH, st)
     dpre1 = ws.ptr("dpre1", (B, Ld)); g1 = ws.ptr("g1", (B, Ld))
     xh1 = ws.ptr(f"xhat1_{tag}", (B, Ld))
-    ops.ln_act_bwd(dz_ptr + 4 * TRUNK_DIM, lddz, None, None, 0, z_ptr + 4 * TRUNK_DIM, ldz, xh1,
-                   ws.ptr(f"rstd1_{tag}", (B,)), store.ptr("LayerNorm_1", "scale"), 0, dpre1, g1, B, Ld, B, True, TANH, st)
+    ops.ln_act_bwd_seg(
+        [(dz_ptr, lddz, z_ptr, ldz, xh0, ws.ptr(f"rstd0_{tag}", (B,)), store.ptr("LayerNorm_0", "scale"), dpre0, g0,
+          TRUNK_DIM),
+         (dz_ptr + 4 * TRUNK_DIM, lddz, z_ptr + 4 * TRUNK_DIM, ldz, xh1, ws.ptr(f"rstd1_{tag}", (B,)),
+          store.ptr("LayerNorm_1", "scale"), dpre1, g1, Ld)],
+        dz_slabs[0], dz_slabs[1], B, TANH, st)
     if gside is not None:
         stw = gside.fork()
     ops.colsum(g0, grads.ptr("LayerNorm_0", "bias"), 1, B, TRUNK_DIM, TRUNK_DIM, 0, stw,
@@ -294,9 +298,11 @@ def ensemble_fwd(cfg: NetConfig, tag, store, m0, mstride, E, inp_ptr, ld_inp, B,
 
 
 def ensemble_bwd(cfg: NetConfig, tag, store, grads, dq_ptr, inp_ptr, ld_inp, B, ws: Workspace, st,
-                 gside: "GradSide | None" = None):
+                 gside: "GradSide | None" = None, dinp="sum"):
     """Backward of the full ensemble from dq (E, B). Writes parameter grads when `grads` is given and
-    returns ptr of dinp (B, latent+action) = sum over members."""
+    returns ptr of dinp (B, latent+action) = sum over members.  dinp="slabs": return (ptr, nslab, slab stride) of
+    the split-K partials instead (the consumer sums them on read: one launch less); dinp=None: the input gradient
+    is not needed (state-based critic step), skip its GEMM."""
     pre = critic_head_prefix(cfg)
     E, ln = cfg.num_qs, cfg.critic_layer_norm
     dims = [cfg.latent + cfg.action_dim] + list(cfg.hidden_dims)
@@ -340,9 +346,17 @@ def ensemble_bwd(cfg: NetConfig, tag, store, grads, dq_ptr, inp_ptr, ld_inp, B, 
             dy_ptr = ws.ptr(f"edh{i - 1}", (E, B, hp))
             ops.gemm(dz, W, dy_ptr, None, E, B, hp, h, a_zs=B * h, a_ms=h, a_ks=1, b_zs=hp * h, b_ks=1, b_ns=h,
                      c_zs=B * hp, c_ms=hp, b_ncontig=False, stream=st)
+        elif dinp is None:
+            return None
         else:
+            want = dinp
             dinp = ws.ptr("dinp", (B, hp))
             ns = _ksplit(E * h)          # few (M, N) tiles and a long K = (member, feature) loop: split it
+            if ns > 1 and want == "slabs":
+                slab = ws.ptr("dinp_slab", (ns, B, hp))
+                ops.gemm(dz, W, slab, None, 1, B, hp, E * h, seglen=h, a_ss=B * h, a_ms=h, a_ks=1, b_ss=hp * h, b_ks=1,
+                         b_ns=h, c_ms=hp, b_ncontig=False, nsplit=ns, c_split_stride=B * hp, stream=st)
+                return slab, ns, B * hp
             if ns > 1:
                 slab = ws.ptr("dinp_slab", (ns, B, hp))
                 ops.gemm(dz, W, slab, None, 1, B, hp, E * h, seglen=h, a_ss=B * h, a_ms=h, a_ks=1, b_ss=hp * h, b_ks=1,
@@ -352,7 +366,7 @@ def ensemble_bwd(cfg: NetConfig, tag, store, grads, dq_ptr, inp_ptr, ld_inp, B, 
             else:
                 ops.gemm(dz, W, dinp, None, 1, B, hp, E * h, seglen=h, a_ss=B * h, a_ms=h, a_ks=1, b_ss=hp * h, b_ks=1,
                          b_ns=h, c_ms=hp, b_ncontig=False, stream=st)
-            return dinp
+            return (dinp, 1, 0) if want == "slabs" else dinp
 
 
 # =============================================================================== policy head

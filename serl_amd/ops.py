@@ -212,6 +212,16 @@ def ln_act_bwd(dy, lddy, dq, w_head, w_gs, y, ldy, xhat, rstd, gamma, pgs, dz, g
          rows_per_group, int(use_ln), act, stream)
 
 
+def ln_act_bwd_seg(segs, dy_nslab, dy_ss, R, act, stream):
+    """segs: list of (dy, lddy, y, ldy, xhat, rstd, gamma, dz, g, N) sharing the rows; dy is summed over dy_nslab slabs."""
+    import ctypes
+    n = len(segs)
+    tabs = {c: ptr_table([sg[c] for sg in segs]) for c in (0, 2, 4, 5, 6, 7, 8)}
+    ints = {c: (ctypes.c_int * n)(*[int(sg[c]) for sg in segs]) for c in (1, 3, 9)}
+    call("serl_ln_act_bwd_seg", n, tabs[0][0], ints[1], int(dy_nslab), int(dy_ss), tabs[2][0], ints[3], tabs[4][0],
+         tabs[5][0], tabs[6][0], tabs[7][0], tabs[8][0], R, ints[9], act, stream)
+
+
 def colsum(x0, out0, ngroups, rows_per_group, N, ldx, out_gs, stream, w=None, mul=None, x1=None, out1=None,
            x2=None, mul2=None, out2=None):
     call("serl_colsum", x0, w, mul, out0, x1, out1, x2, mul2, out2, ngroups, rows_per_group, N, ldx, out_gs, stream)
