@@ -101,6 +101,13 @@ int serl_ln_act_head_fwd(const float* pre, int nslab, long long pre_slab_stride,
                          float* xhat, float* rstd, int R, int N, int rows_per_group, int use_ln, int act,
                          const float* head_w, long long head_w_group_stride, const float* head_b,
                          long long head_b_group_stride, float* q, void* stream);
+/* PixelMultiplexer trunk behind the split-K GEMM of Dense_0 (serl/networks/pixel_multiplexer.py:34-43), one launch:
+ * y0 = act(LN(sum of nslab partials + bias0)) (N0 columns) and the state branch y1 = act(LN(x1[:, :K1] W1 + bias1))
+ * (N1 columns, the K1-term products in fp32 FMA); y0 / y1 share the row stride ldy (columns of the same z matrix). */
+int serl_trunk_ln_fwd(const float* slab, int nslab, long long slab_stride, int N0, const float* bias0,
+                      const float* gamma0, const float* beta0, float* y0, float* xhat0, float* rstd0, const float* x1,
+                      int ldx1, int K1, const float* W1, int N1, const float* bias1, const float* gamma1,
+                      const float* beta1, float* y1, float* xhat1, float* rstd1, int ldy, int R, int act, void* stream);
 int serl_ln_act_bwd(const float* dy, int lddy, const float* dq, const float* w_head, long long w_group_stride,
                     const float* y, int ldy, const float* xhat, const float* rstd, const float* gamma,
                     long long param_group_stride, float* dz, float* g, int R, int N, int rows_per_group, int use_ln,

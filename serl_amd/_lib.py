@@ -36,6 +36,8 @@ _SIGS = {
     "serl_ln_act_head_fwd": [c_p, c_i, c_ll, c_i, c_p, c_p, c_p, c_ll, c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i,
                              c_p, c_ll, c_p, c_ll, c_p, c_p],
     "serl_ln_act_bwd": [c_p, c_i, c_p, c_p, c_ll, c_p, c_i, c_p, c_p, c_p, c_ll, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
+    "serl_trunk_ln_fwd": [c_p, c_i, c_ll, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_p,
+                          c_p, c_p, c_i, c_i, c_i, c_p],
     "serl_ln_act_bwd_seg": [c_i, PP, PI, c_i, c_ll, PP, PI, PP, PP, PP, PP, PP, c_i, PI, c_i, c_p],
     "serl_colsum": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_ll, c_p],
     "serl_rowdot": [c_p, c_p, c_ll, c_p, c_ll, c_p, c_i, c_i, c_i, c_p],

@@ -113,6 +113,81 @@ extern "C" int serl_ln_act_head_fwd(const float* pre, int nslab, long long pre_s
   return SERL_OK;
 }
 
+// PixelMultiplexer trunk (serl/networks/pixel_multiplexer.py:34-43) behind the split-K GEMM of Dense_0, one launch:
+//   blockIdx.y = 0:  y0 = act(LN(sum of nslab partials + bias0))                      (image branch, N0 columns)
+//   blockIdx.y = 1:  y1 = act(LN(x1[row, :K1] . W1[K1][N1] + bias1))                  (state branch: K1 ~ 19, fp32 FMA)
+struct TrunkLnArgs {
+  const float* slab; long long slab_ss; int nslab; int N0;
+  const float* bias0; const float* gamma0; const float* beta0; float* y0; float* xhat0; float* rstd0;
+  const float* x1; int ldx1; int K1; const float* W1; int N1;
+  const float* bias1; const float* gamma1; const float* beta1; float* y1; float* xhat1; float* rstd1;
+  int ldy, R, act;
+};
+__global__ __launch_bounds__(256) void trunk_ln_fwd_kernel(const TrunkLnArgs a) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= a.R) return;
+  const bool img = blockIdx.y == 0;
+  const int N = img ? a.N0 : a.N1;
+  const float* bias = img ? a.bias0 : a.bias1;
+  const float* gamma = img ? a.gamma0 : a.gamma1;
+  const float* beta = img ? a.beta0 : a.beta1;
+  float* y = img ? a.y0 : a.y1;
+  float* xhat = img ? a.xhat0 : a.xhat1;
+  float* rstd = img ? a.rstd0 : a.rstd1;
+  float z[MAXW];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXW; ++i) {
+    const int n = lane + 64 * i;
+    float v = 0.f;
+    if (n < N) {
+      if (img) {
+        const float* src = a.slab + (long long)row * a.N0 + n;
+#pragma unroll 8
+        for (int s = 0; s < a.nslab; ++s) v += src[s * a.slab_ss];
+      } else {
+        const float* xr = a.x1 + (long long)row * a.ldx1;
+        for (int k = 0; k < a.K1; ++k) v = fmaf(xr[k], a.W1[k * a.N1 + n], v);
+      }
+      v += bias[n];
+    }
+    z[i] = v;
+    s1 += v;
+    s2 += v * v;
+  }
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
+  const float mean = s1 / (float)N;
+  const float mul = rsqrtf(fmaxf(s2 / (float)N - mean * mean, 0.f) + LN_EPS);
+  if (rstd && lane == 0) rstd[row] = mul;
+#pragma unroll
+  for (int i = 0; i < MAXW; ++i) {
+    const int n = lane + 64 * i;
+    if (n < N) {
+      const float xh = (z[i] - mean) * mul;
+      if (xhat) xhat[(long long)row * N + n] = xh;
+      float v = (z[i] - mean) * (mul * gamma[n]) + beta[n];
+      if (a.act == ACT_RELU) v = fmaxf(v, 0.f);
+      else if (a.act == ACT_TANH) v = tanhf(v);
+      y[(long long)row * a.ldy + n] = v;
+    }
+  }
+}
+extern "C" int serl_trunk_ln_fwd(const float* slab, int nslab, long long slab_stride, int N0, const float* bias0,
+                                 const float* gamma0, const float* beta0, float* y0, float* xhat0, float* rstd0,
+                                 const float* x1, int ldx1, int K1, const float* W1, int N1, const float* bias1,
+                                 const float* gamma1, const float* beta1, float* y1, float* xhat1, float* rstd1,
+                                 int ldy, int R, int act, void* stream) {
+  SERL_CHECK_ARG(slab && bias0 && gamma0 && beta0 && y0 && x1 && W1 && bias1 && gamma1 && beta1 && y1, "trunk_ln_fwd: null pointer");
+  SERL_CHECK_ARG(nslab >= 1 && R >= 1 && K1 >= 1 && N0 >= 1 && N0 <= 64 * MAXW && N1 >= 1 && N1 <= 64 * MAXW,
+                 "trunk_ln_fwd: bad sizes (N0, N1 must be <= %d)", 64 * MAXW);
+  TrunkLnArgs a{slab, slab_stride, nslab, N0, bias0, gamma0, beta0, y0, xhat0, rstd0, x1, ldx1, K1, W1, N1,
+                bias1, gamma1, beta1, y1, xhat1, rstd1, ldy, R, act};
+  hipLaunchKernelGGL(trunk_ln_fwd_kernel, dim3(cdiv(R, 4), 2), dim3(256), 0, (hipStream_t)stream, a);
+  SERL_CHECK_LAUNCH("trunk_ln_fwd");
+  return SERL_OK;
+}
+
 // Backward of act(LN(z)): g = dy * act'(y); dxhat = g*gamma;
 // dz = rstd * (dxhat - mean(dxhat) - xhat*mean(dxhat*xhat)).  dy is either a dense (R,N) matrix with
 // row stride lddy, or the rank-1 form dq[row] * w[e][n] (gradient through a Dense(1) head).

@@ -215,18 +215,17 @@ def trunk_fwd(cfg: NetConfig, tag, store, state_ptr, z_ptr, ldz, B, ws: Workspac
     slab = ws.ptr(f"slab0_{tag}", (ns, B, TRUNK_DIM))
     ops.gemm(ws.ptr(f"enc_{tag}", (B, K)), store.ptr("Dense_0", "kernel"), slab, None, 1, B, TRUNK_DIM, K,
              a_ms=K, a_ks=1, b_ks=TRUNK_DIM, b_ns=1, c_ms=TRUNK_DIM, nsplit=ns, c_split_stride=B * TRUNK_DIM, stream=st)
-    ops.ln_act_fwd(slab, ns, B * TRUNK_DIM, TRUNK_DIM, store.ptr("Dense_0", "bias"), store.ptr("LayerNorm_0", "scale"),
-                   store.ptr("LayerNorm_0", "bias"), 0, z_ptr, ldz,
-                   ws.ptr(f"xhat0_{tag}", (B, TRUNK_DIM)) if save else None,
-                   ws.ptr(f"rstd0_{tag}", (B,)) if save else None, B, TRUNK_DIM, B, True, TANH, st)
+    # one launch: slab sum + bias + LN + tanh of the image branch, and the whole state branch (Dense_1 has K = state_dim
+    # ~ 19 terms per output: computed inline in fp32) -- instead of ln_act + gemm + ln_act on the latency-bound chain
     Ld, Sd = cfg.latent_dim, cfg.state_dim
-    pre1 = ws.ptr(f"pre1_{tag}", (B, Ld))
-    ops.gemm(state_ptr, store.ptr("Dense_1", "kernel"), pre1, None, 1, B, Ld, Sd, a_ms=Sd, a_ks=1, b_ks=Ld, b_ns=1,
-             c_ms=Ld, stream=st)
-    ops.ln_act_fwd(pre1, 1, 0, Ld, store.ptr("Dense_1", "bias"), store.ptr("LayerNorm_1", "scale"),
-                   store.ptr("LayerNorm_1", "bias"), 0, z_ptr + 4 * TRUNK_DIM, ldz,
-                   ws.ptr(f"xhat1_{tag}", (B, Ld)) if save else None, ws.ptr(f"rstd1_{tag}", (B,)) if save else None,
-                   B, Ld, B, True, TANH, st)
+    ops.trunk_ln_fwd(slab, ns, B * TRUNK_DIM, TRUNK_DIM, store.ptr("Dense_0", "bias"), store.ptr("LayerNorm_0", "scale"),
+                     store.ptr("LayerNorm_0", "bias"), z_ptr,
+                     ws.ptr(f"xhat0_{tag}", (B, TRUNK_DIM)) if save else None,
+                     ws.ptr(f"rstd0_{tag}", (B,)) if save else None,
+                     state_ptr, Sd, Sd, store.ptr("Dense_1", "kernel"), Ld, store.ptr("Dense_1", "bias"),
+                     store.ptr("LayerNorm_1", "scale"), store.ptr("LayerNorm_1", "bias"), z_ptr + 4 * TRUNK_DIM,
+                     ws.ptr(f"xhat1_{tag}", (B, Ld)) if save else None, ws.ptr(f"rstd1_{tag}", (B,)) if save else None,
+                     ldz, B, TANH, st)
 
 
 def trunk_bwd(cfg: NetConfig, tag, store, grads, state_ptr, z_ptr, ldz, dz_ptr, lddz, B, ws: Workspace, st, need_denc,

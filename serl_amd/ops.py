@@ -212,6 +212,12 @@ def ln_act_bwd(dy, lddy, dq, w_head, w_gs, y, ldy, xhat, rstd, gamma, pgs, dz, g
          rows_per_group, int(use_ln), act, stream)
 
 
+def trunk_ln_fwd(slab, nslab, slab_ss, N0, bias0, gamma0, beta0, y0, xhat0, rstd0, x1, ldx1, K1, W1, N1, bias1, gamma1,
+                 beta1, y1, xhat1, rstd1, ldy, R, act, stream):
+    call("serl_trunk_ln_fwd", slab, nslab, slab_ss, N0, bias0, gamma0, beta0, y0, xhat0, rstd0, x1, ldx1, K1, W1, N1,
+         bias1, gamma1, beta1, y1, xhat1, rstd1, ldy, R, act, stream)
+
+
 def ln_act_bwd_seg(segs, dy_nslab, dy_ss, R, act, stream):
     """segs: list of (dy, lddy, y, ldy, xhat, rstd, gamma, dz, g, N) sharing the rows; dy is summed over dy_nslab slabs."""
     import ctypes
