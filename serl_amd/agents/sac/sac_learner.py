@@ -161,7 +161,7 @@ class SACLearner(Agent):
             ss = self._shared["side_streams"] = dict(
                 s=[torch.cuda.Stream(), torch.cuda.Stream()],
                 fork=torch.cuda.Event(), join=[torch.cuda.Event(), torch.cuda.Event()],
-                actor=torch.cuda.Stream(), astart=torch.cuda.Event(), agate=torch.cuda.Event(), adone=[], cdone=[])
+                actor=torch.cuda.Stream(), astart=torch.cuda.Event(), agate=torch.cuda.Event(), aobs=torch.cuda.Event(), adone=[], cdone=[])
         return ss
 
     def _target_members(self, key):
@@ -265,10 +265,13 @@ class SACLearner(Agent):
             _, rng = prng.split(rng)                       # target dropout key (consumed, unused)
             _, rng = prng.split(rng)                       # critic dropout key
             step_keys.append((key_act, key_sub))
+        key_pi, rng = prng.split(rng)                      # actor step (sac_learner.py:121-122): policy sample key
+        _, rng = prng.split(rng)                           # ... and its critic dropout key
         ss = self._side_streams()
         main = torch.cuda.current_stream()
         s0, s1 = ss["s"]
         zT_all = nlogp_all = None
+        zP = ws.ptr("zC_pi", (B, ldz)) if ACTOR_RUNAHEAD else zC     # critic input of the actor step
         # pixel learners: fused gather + crop of the minibatch rows (feats["crop"]).  With the run-ahead stream only the
         # first minibatch is augmented up front; minibatch j+1 is augmented on that stream during critic step j.
         crop = feats.get("crop")
@@ -302,6 +305,12 @@ class SACLearner(Agent):
                               zT_all + 4 * (j * B * ldz + cfg.latent), ldz, want_logp=self.backup_entropy,
                               logp_out=nlogp_all + 4 * j * B)
                 adone[j].record(astream)
+            def enqueue_actor_obs():
+                self._features([("A", actor.store, "obs")], feats, (utd_ratio - 1) * B, B, ws, sta, save_tag="A",
+                               prep=False)
+                nn.policy_fwd(cfg, "A", actor.store, zA, ldz, B, ws, sta, key_pi, rank * B, Bg, zP + 4 * cfg.latent,
+                              ldz, save=True)
+                ss["aobs"].record(astream)
             # the host interleaves the two streams' launches (pass j+1 is enqueued inside critic step j): enqueued all
             # up front, the main stream would sit empty while the host is busy with the actor stream's 500 launches
             enqueue_actor(0)
@@ -324,11 +333,13 @@ class SACLearner(Agent):
                                feats, lo, B, ws, st, save_tag="C", trunk_streams={"C": s1}, fork=ss["fork"],
                                z_ptrs={"T": zT})
                 ops.phase("features_fwd")
+                if ACTOR_GATE:           # start pass i+1 when the main stream leaves its (HBM-bound) encoder forward
+                    ss["agate"].record(main)
+                    astream.wait_event(ss["agate"])
                 if i + 1 < utd_ratio:
-                    if ACTOR_GATE:       # start pass i+1 when the main stream leaves its (HBM-bound) encoder forward
-                        ss["agate"].record(main)
-                        astream.wait_event(ss["agate"])
                     enqueue_actor(i + 1)
+                else:                    # behind the last pass: the actor's pass over obs for the actor step
+                    enqueue_actor_obs()
                 main.wait_event(ss["adone"][i])
                 nlogp = nlogp_all + 4 * i * B if self.backup_entropy else None
             else:
@@ -393,11 +404,17 @@ class SACLearner(Agent):
         # ---- actor step on the last minibatch (sac_learner.py:120-144, 235)
         ops.phase("actor")
         lo = (utd_ratio - 1) * B
-        key_pi, rng = prng.split(rng)
-        _, rng = prng.split(rng)                           # critic dropout key
-        self._features([("A", actor.store, "obs"), ("C", critic.store, "obs")], feats, lo, B, ws, st, save_tag="A")
-        logp = nn.policy_fwd(cfg, "A", actor.store, zA, ldz, B, ws, st, key_pi, rank * B, Bg, zC + 4 * cfg.latent, ldz,
-                             save=True)
+        if ACTOR_RUNAHEAD:
+            # the actor's own pass over obs (encoder, trunk, policy sample) ran ahead behind the last next_obs pass;
+            # only the critic pass with the post-UTD critic parameters is left on the main stream
+            main.wait_event(ss["aobs"])
+            self._features([("C", critic.store, "obs")], feats, lo, B, ws, st, z_ptrs={"C": zP})
+            logp = ws.ptr("logp_A", (B,))
+        else:
+            self._features([("A", actor.store, "obs"), ("C", critic.store, "obs")], feats, lo, B, ws, st, save_tag="A")
+            logp = nn.policy_fwd(cfg, "A", actor.store, zA, ldz, B, ws, st, key_pi, rank * B, Bg, zP + 4 * cfg.latent,
+                                 ldz, save=True)
+        zC = zP                                            # critic input of the actor step
         q = nn.ensemble_fwd(cfg, "C", critic.store, 0, 1, E, zC, ldz, B, ws, st, save=True)
         ops.actor_loss(q, E, B, logp, log_temp, info.data_ptr() + 8, st)
         dq = ws.ptr("dq", (E, B))
