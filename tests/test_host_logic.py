@@ -184,3 +184,19 @@ def test_oracle_ddpg_update_and_noise():
     key = prng.split(new["rng"])[0]
     np.testing.assert_allclose(a - a0, 0.05 * prng.normal(key, (2,)), atol=1e-6)
     assert np.array_equal(st2["rng"], st3["rng"])
+
+
+def test_update_info_is_a_lazy_mapping():
+    """update() returns its scalars as a Mapping that reads the device buffer on first access (like the reference's
+    jax Arrays); keys, order, dict() / == / iteration behave like the reference's dict."""
+    from serl_amd.agents.sac.sac_learner import UpdateInfo
+    raw = torch.tensor([8.0, 4.0, -6.0, 0.0, 0.25, 0.5, 1.5, 0.0])      # loss sum, q sum, actor-loss sum, -, temp, temp loss, entropy
+    info = UpdateInfo(raw, global_batch=2, num_qs=2)
+    assert info._host is None                                            # nothing fetched yet
+    assert list(info) == ["actor_loss", "entropy", "critic_loss", "q", "temperature", "temperature_loss"]
+    assert info["critic_loss"] == 2.0 and info["q"] == 1.0 and info["actor_loss"] == -3.0 and info["entropy"] == 1.5
+    assert dict(info) == {"actor_loss": -3.0, "entropy": 1.5, "critic_loss": 2.0, "q": 1.0, "temperature": 0.25,
+                          "temperature_loss": 0.5}
+    assert info == dict(info) and len(info) == 6 and {f"training/{k}": v for k, v in info.items()}
+    ddpg = UpdateInfo(raw, 2, 1, keys=("actor_loss", "critic_loss", "q"))
+    assert list(ddpg.items()) == [("actor_loss", -3.0), ("critic_loss", 4.0), ("q", 2.0)]
