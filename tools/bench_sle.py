@@ -1,0 +1,19 @@
+"""HIP-event timing of sle_fwd at the bench shapes (4 groups, B=256, 7x7x256 S-format features)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from serl_amd import ops
+G, B, HW, C = int(os.environ.get("SLE_G", "4")), 256, 49, 256
+dev = "cuda"
+feat = [torch.randint(0, 30000, (B * HW * 2 * C,), dtype=torch.int16, device=dev) for _ in range(G)]
+ker = [torch.randn(HW * C * 8, device=dev) for _ in range(G)]
+out = [torch.zeros(B, 4096, device=dev) for _ in range(G)]
+st = ops.current_stream()
+fn = lambda: ops.sle_fwd([t.data_ptr() for t in feat], [t.data_ptr() for t in ker], [t.data_ptr() for t in out], 4096, B, HW, C, 8, st, feat_split=True)
+for _ in range(5): fn()
+torch.cuda.synchronize()
+a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+a.record()
+for _ in range(50): fn()
+b.record(); torch.cuda.synchronize()
+print(f"sle_fwd G={G}: {a.elapsed_time(b) / 50 * 1e3:.1f} us")
