@@ -46,6 +46,59 @@ __global__ __launch_bounds__(256) void sle_fwd_kernel(const SleFwdArgs a, int ld
   for (int f = 0; f < SLE_F; ++f) op[f] = acc[f];
 }
 
+// Variant for the bench shapes: block = 32 channels x 8 slices of hw, for SLE_NB images.  The kernel[hw, c, :] row is
+// loaded once per SLE_NB images (one image per thread makes every block re-read the whole 400 KB kernel from L2,
+// 8x the feature bytes) and the hw loop is 8x shorter; the 8 slice partials are summed through LDS in a fixed order.
+#define SLE_NB 4
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void sle_fwd_sliced_kernel(const SleFwdArgs a, int ldo, int B, int HW, int C) {
+  __shared__ float part[8][SLE_NB * 32 * SLE_F + 8];
+  const void* __restrict__ feat = a.feat[blockIdx.z];
+  const float* __restrict__ ker = a.ker[blockIdx.z];
+  float* __restrict__ out = a.out[blockIdx.z];
+  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl, b0 = blockIdx.y * SLE_NB;
+  const int per = (HW + 7) / 8;
+  const int hw0 = sl * per, hw1 = min(HW, hw0 + per);
+  float acc[SLE_NB][SLE_F];
+#pragma unroll
+  for (int j = 0; j < SLE_NB; ++j)
+#pragma unroll
+    for (int f = 0; f < SLE_F; ++f) acc[j][f] = 0.f;
+  if (c < C) {
+    const float4* kp = (const float4*)(ker + (long long)c * SLE_F);
+    for (int hw = hw0; hw < hw1; ++hw) {
+      const float4 k0 = kp[(long long)hw * C * 2], k1 = kp[(long long)hw * C * 2 + 1];
+#pragma unroll
+      for (int j = 0; j < SLE_NB; ++j) {
+        const int b = b0 + j < B ? b0 + j : B - 1;          // clamped: tail images are computed and not stored
+        const float x = feat_at<SPLIT>(feat, (long long)b * HW + hw, C, c);
+        acc[j][0] += x * k0.x; acc[j][1] += x * k0.y; acc[j][2] += x * k0.z; acc[j][3] += x * k0.w;
+        acc[j][4] += x * k1.x; acc[j][5] += x * k1.y; acc[j][6] += x * k1.z; acc[j][7] += x * k1.w;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < SLE_NB; ++j)
+#pragma unroll
+    for (int f = 0; f < SLE_F; ++f) part[sl][(j * 32 + cl) * SLE_F + f] = acc[j][f];
+  __syncthreads();
+  // SLE_NB * 32 * 8 = 1024 outputs per block, 4 per thread: (image j, channel cl2, features f4..f4+3)
+  for (int o = threadIdx.x; o < SLE_NB * 32 * SLE_F / 4; o += 256) {
+    const int j = o / (32 * SLE_F / 4), rem = o - j * (32 * SLE_F / 4);      // rem = cl2 * 2 + half
+    const int cc = blockIdx.x * 32 + (rem >> 1);
+    if (b0 + j < B && cc < C) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int s8 = 0; s8 < 8; ++s8) {
+        const float4 p4 = *reinterpret_cast<const float4*>(&part[s8][(j * 32 * SLE_F) + rem * 4]);
+        v.x += p4.x; v.y += p4.y; v.z += p4.z; v.w += p4.w;
+      }
+      *reinterpret_cast<float4*>(out + (long long)(b0 + j) * ldo + (long long)blockIdx.x * 32 * SLE_F + rem * 4) = v;
+    }
+  }
+}
+
 extern "C" int serl_sle_fwd(int ngroups, const void* const* feat, const float* const* ker, float* const* out, int ldo,
                             int B, int HW, int C, int F, int feat_split, void* stream) {
   SERL_CHECK_ARG(ngroups >= 1 && ngroups <= SLE_MAXG, "sle_fwd: ngroups must be in [1,%d]", SLE_MAXG);
@@ -55,6 +108,17 @@ extern "C" int serl_sle_fwd(int ngroups, const void* const* feat, const float* c
   for (int i = 0; i < ngroups; ++i) {
     SERL_CHECK_ARG(feat[i] && ker[i] && out[i] && (((uintptr_t)ker[i]) & 15) == 0, "sle_fwd: null or unaligned (16 B) pointer");
     a.feat[i] = feat[i]; a.ker[i] = ker[i]; a.out[i] = out[i];
+  }
+  bool aligned = (ldo & 3) == 0;
+  for (int i = 0; i < ngroups; ++i) aligned = aligned && (((uintptr_t)out[i]) & 15) == 0;
+  if (aligned && B >= 64 && HW >= 16) {            // enough work per block: the sliced variant
+    const dim3 g2(cdiv(C, 32), cdiv(B, SLE_NB), ngroups);
+    if (feat_split)
+      hipLaunchKernelGGL(sle_fwd_sliced_kernel<true>, g2, dim3(256), 0, (hipStream_t)stream, a, ldo, B, HW, C);
+    else
+      hipLaunchKernelGGL(sle_fwd_sliced_kernel<false>, g2, dim3(256), 0, (hipStream_t)stream, a, ldo, B, HW, C);
+    SERL_CHECK_LAUNCH("sle_fwd");
+    return SERL_OK;
   }
   const dim3 grid(cdiv(B * C, 256), ngroups);
   if (feat_split)

@@ -362,7 +362,7 @@ def test_sle(dev, B, HW, C):
     _sle_case(dev, B, HW, C, False)
 
 
-@pytest.mark.parametrize("B,HW,C", [(5, 49, 256), (3, 30, 32)])
+@pytest.mark.parametrize("B,HW,C", [(5, 49, 256), (3, 30, 32), (70, 49, 72), (66, 17, 32)])   # B >= 64: sliced kernel
 def test_sle_split_features(dev, B, HW, C):
     _sle_case(dev, B, HW, C, True)
 
