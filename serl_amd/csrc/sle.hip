@@ -162,6 +162,50 @@ __global__ __launch_bounds__(256) void sle_bwd_data_kernel(const SleBwdArgs a, i
   }
 }
 
+// Sliced variant (as sle_fwd_sliced_kernel): block = 32 channels x 8 hw slices for SLE_NB images; every (b, hw, c) output
+// is independent, the kernel row is loaded once per SLE_NB images and the hw loop is 8x shorter.
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void sle_bwd_data_sliced_kernel(const SleBwdArgs a, int ldo, int B, int HW, int C) {
+  const float* __restrict__ dout = a.dout[blockIdx.z];
+  const float* __restrict__ ker = a.ker[blockIdx.z];
+  const void* __restrict__ feat = a.feat[blockIdx.z];
+  void* __restrict__ dfeat = a.dfeat[blockIdx.z];
+  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl, b0 = blockIdx.y * SLE_NB;
+  if (c >= C) return;
+  const int per = (HW + 7) / 8;
+  const int hw0 = sl * per, hw1 = min(HW, hw0 + per);
+  float d[SLE_NB][SLE_F];
+#pragma unroll
+  for (int j = 0; j < SLE_NB; ++j) {
+    const int b = b0 + j < B ? b0 + j : B - 1;
+    const float* dp = dout + (long long)b * ldo + c * SLE_F;
+#pragma unroll
+    for (int f = 0; f < SLE_F; ++f) d[j][f] = dp[f];
+  }
+  const float4* kp = (const float4*)(ker + (long long)c * SLE_F);
+  for (int hw = hw0; hw < hw1; ++hw) {
+    const float4 k0 = kp[(long long)hw * C * 2], k1 = kp[(long long)hw * C * 2 + 1];
+#pragma unroll
+    for (int j = 0; j < SLE_NB; ++j) {
+      if (b0 + j >= B) break;
+      float s = d[j][0] * k0.x;
+      s += d[j][1] * k0.y; s += d[j][2] * k0.z; s += d[j][3] * k0.w;
+      s += d[j][4] * k1.x; s += d[j][5] * k1.y; s += d[j][6] * k1.z; s += d[j][7] * k1.w;
+      const long long pix = (long long)(b0 + j) * HW + hw;
+      const float v = feat_at<SPLIT>(feat, pix, C, c) > 0.f ? s : 0.f;
+      if constexpr (SPLIT) {
+        uint32_t h, l;
+        split_pair(v, 0.f, h, l);
+        unsigned short* o = (unsigned short*)dfeat + pix * 2 * C + c;
+        o[0] = (unsigned short)h; o[C] = (unsigned short)l;
+      } else {
+        ((float*)dfeat)[pix * C + c] = v;
+      }
+    }
+  }
+}
+
 // dker[hw,c,f] = sum_b feat[b,hw,c] * dout[b, c*F+f]; block = 64 channels x 4 batch lanes, fixed-order LDS sum.
 template <bool SPLIT>
 __global__ __launch_bounds__(256) void sle_bwd_kernel_kernel(const SleBwdArgs a, int ldo, int B, int HW, int C) {
@@ -205,7 +249,14 @@ extern "C" int serl_sle_bwd(int ngroups, const float* const* dout, int ldo, cons
     a.dout[i] = dout[i]; a.ker[i] = ker[i]; a.feat[i] = feat[i];
     a.dfeat[i] = dfeat ? dfeat[i] : nullptr; a.dker[i] = dker ? dker[i] : nullptr;
   }
-  if (dfeat) {
+  if (dfeat && B >= 64 && HW >= 16) {
+    const dim3 g2(cdiv(C, 32), cdiv(B, SLE_NB), ngroups);
+    if (feat_split)
+      hipLaunchKernelGGL(sle_bwd_data_sliced_kernel<true>, g2, dim3(256), 0, st, a, ldo, B, HW, C);
+    else
+      hipLaunchKernelGGL(sle_bwd_data_sliced_kernel<false>, g2, dim3(256), 0, st, a, ldo, B, HW, C);
+    SERL_CHECK_LAUNCH("sle_bwd_data");
+  } else if (dfeat) {
     const dim3 grid(cdiv(B * C, 256), ngroups);
     if (feat_split)
       hipLaunchKernelGGL(sle_bwd_data_kernel<true>, grid, dim3(256), 0, st, a, ldo, B, HW, C);

@@ -357,7 +357,7 @@ def test_rowdot_and_rank1_bwd(dev):
 
 
 # ---------------------------------------------------------------------------------- SLE
-@pytest.mark.parametrize("B,HW,C", [(5, 49, 256), (3, 30, 32), (2, 7, 70)])
+@pytest.mark.parametrize("B,HW,C", [(5, 49, 256), (3, 30, 32), (2, 7, 70), (67, 49, 40)])   # B >= 64: sliced kernels
 def test_sle(dev, B, HW, C):
     _sle_case(dev, B, HW, C, False)
 
