@@ -23,34 +23,57 @@ static int make_geom(ConvGeom& g, int B, int IH, int IW, int C, int KH, int KW, 
   return SERL_OK;
 }
 
-// out[g][e] = sum_s slab[g][s][e]; rows < KKC go to dW, the last row to dbias. 16 elements x 16 slab lanes.
+// out[g][e] = sum_s slab[g][s][e]; rows < KKC go to dW, the last row to dbias.  Block = 64 lanes x float4 (256
+// consecutive elements: 1 KB coalesced per slab row) x 4 slab lanes; lane sl sums slabs sl, sl+4, ... with independent
+// loads in flight, then the 4 partials are added in a fixed order (reproducible, no atomics).  F % 4 == 0.
 struct ReduceArgs {
   const float* slab; float* dw[MAXG]; float* db[MAXG];
   int nsplit, kkc, F;
 };
+template <int V>
 static __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const ReduceArgs a) {
-  // 16 elements x 16 slab lanes per block; lane sl sums slabs sl, sl+16, ... (independent loads in flight),
-  // then the 16 partials are added in a fixed order.
-  __shared__ float part[16][17];
+  __shared__ float part[4][64][V];
   const int gi = blockIdx.y;
   const int nel = (a.kkc + 1) * a.F;
-  const int e = threadIdx.x & 15, sl = threadIdx.x >> 4;
-  const int el = blockIdx.x * 16 + e;
+  const int ln = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int el = (blockIdx.x * 64 + ln) * V;
   const float* base = a.slab + (size_t)gi * a.nsplit * (size_t)nel;
-  float s = 0.f;
+  float s[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) s[j] = 0.f;
   if (el < nel) {
 #pragma unroll 8
-    for (int k = sl; k < a.nsplit; k += 16) s += base[(size_t)k * nel + el];
+    for (int k = sl; k < a.nsplit; k += 4) {
+      const float* src = base + (size_t)k * nel + el;
+      if constexpr (V == 4) {
+        const float4 v = *reinterpret_cast<const float4*>(src);
+        s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+      } else {
+        s[0] += *src;
+      }
+    }
   }
-  part[sl][e] = s;
+#pragma unroll
+  for (int j = 0; j < V; ++j) part[sl][ln][j] = s[j];
   __syncthreads();
   if (sl == 0 && el < nel) {
-    float v = 0.f;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) v += part[k][e];
-    if (el < a.kkc * a.F) a.dw[gi][el] = v;
-    else a.db[gi][el - a.kkc * a.F] = v;
+    for (int k = 1; k < 4; ++k)
+#pragma unroll
+      for (int j = 0; j < V; ++j) s[j] += part[k][ln][j];
+    float* dst = el < a.kkc * a.F ? a.dw[gi] + el : a.db[gi] + (el - a.kkc * a.F);
+    if constexpr (V == 4) *reinterpret_cast<float4*>(dst) = make_float4(s[0], s[1], s[2], s[3]);
+    else *dst = s[0];
   }
+}
+
+// Vector variant when F % 4 == 0 (so a float4 never straddles dW / dbias) and every pointer is 16-byte aligned.
+static inline void launch_wgrad_reduce(const ReduceArgs& ra, int ngroups, hipStream_t st) {
+  const int nel = (ra.kkc + 1) * ra.F;
+  bool v4 = ra.F % 4 == 0 && ((uintptr_t)ra.slab & 15) == 0;
+  for (int i = 0; i < ngroups; ++i) v4 = v4 && (((uintptr_t)ra.dw[i] | (uintptr_t)ra.db[i]) & 15) == 0;
+  if (v4) hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3((nel + 255) / 256, ngroups), dim3(256), 0, st, ra);
+  else hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3((nel + 63) / 64, ngroups), dim3(256), 0, st, ra);
 }
 
 #ifndef WGRAD_BLOCKS

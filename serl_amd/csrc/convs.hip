@@ -608,8 +608,7 @@ extern "C" int serl_convs_wgrad(int ngroups, const void* const* x, const void* c
   if (e) return e;
   ReduceArgs ra; ra.slab = workspace; ra.nsplit = nsplit; ra.kkc = kkc; ra.F = F;
   for (int i = 0; i < ngroups; ++i) { ra.dw[i] = dw[i]; ra.db[i] = dbias[i]; }
-  dim3 grid(cdiv((kkc + 1) * F, 16), ngroups);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, grid, dim3(256), 0, st, ra);
+  launch_wgrad_reduce(ra, ngroups, st);
   SERL_CHECK_LAUNCH("wgrad_reduce");
   return SERL_OK;
 }
