@@ -162,6 +162,12 @@ int serl_gather_window(const unsigned char* frames, long long cap, const long lo
                        int HW3, int S, void* stream);
 /* (dy,dx) = jax.random.randint(split(key, n_total)[row], (2,), 0, 2*pad+1), augmentations.py:6,46 */
 int serl_crop_offsets(unsigned k0, unsigned k1, int n, int row_offset, int n_total, int pad, int* out, void* stream);
+/* device-resident sampling, Dataset.sample_jax serl/data/dataset.py:106-129 (GPUReplayBuffer.get_iterator,
+ * serl/data/replay_buffer.py:149-152): out (n,) int32 = jax.random.randint(key, (n,), minval, maxval) in device
+ * memory, *out_max (device, may be NULL) = out.max(); take_rows = jnp.take(src, indx, axis=0) on rows of row_bytes. */
+int serl_prng_randint(unsigned k0, unsigned k1, int n, int minval, int maxval, int* out, int* out_max, void* stream);
+int serl_take_rows(const void* src, long long nrows, long long row_bytes, const int* indx, void* out, int n,
+                   void* stream);
 
 /* ---- host-side jax.random key plumbing (no GPU needed): split / bits / choice(replace=False),
  * sac_learner.py:64,121-122,168-198; serl/networks/ensemble.py:28 */

@@ -91,8 +91,10 @@ def randint(key, shape, minval: int, maxval: int) -> np.ndarray:
     hi = random_bits(k1, shape)
     lo = random_bits(k2, shape)
     span = U32(maxval - minval) if maxval > minval else U32(1)
-    mult = U32((1 << 16) % int(span))
-    mult = U32((int(mult) * int(mult)) % int(span))
+    # jax/_src/random.py:_randint: multiplier = 2^16 % span, then (multiplier * multiplier) % span -- all in
+    # uint32, so for span > 2^16 the product 2^32 wraps to 0 (the high word then drops out); restated as is.
+    mult = (1 << 16) % int(span)
+    mult = U32(((mult * mult) & 0xFFFFFFFF) % int(span))
     with np.errstate(over="ignore"):
         off = ((hi % span) * mult + (lo % span)).astype(U32) % span
     return (np.int64(minval) + off.astype(np.int64)).astype(np.int32)

@@ -69,6 +69,33 @@ def ring_sample(buf, rng, batch_size, indx=None):
     return _take(buf["data"], indx), indx
 
 
+def ring_upload(buf, block):
+    """replay_buffer.py:141-147 (GPUReplayBuffer.upload): a block of rows at the insert index."""
+    n = len(block["rewards"])
+    lo = buf["head"]
+    assert lo + n <= buf["capacity"]
+
+    def put(store, item):
+        if isinstance(store, dict):
+            for k in item:
+                put(store[k], item[k])
+        else:
+            store[lo:lo + n] = item
+    put(buf["data"], block)
+    buf["head"] = (lo + n) % buf["capacity"]
+    buf["size"] = min(buf["size"] + n, buf["capacity"])
+
+
+def ring_sample_jax(buf, key, batch_size):
+    """dataset.py:116-129 (sample_jax): `key, rng = split(rng)`; indx = randint(key, (B,), 0, len);
+    returns (new rng, indx.max(), gathered batch, indx).  Index stream = oracle.prng's restatement of
+    jax.random.randint (parity unpinned beyond the threefry KATs)."""
+    from . import prng
+    sub, rng = prng.split(key)
+    indx = prng.randint(sub, (batch_size,), 0, buf["size"])
+    return rng, int(indx.max()), _take(buf["data"], indx), indx
+
+
 # ------------------------------------------------------------------ memory-efficient buffer
 def new_frame_buffer(obs_spec, act_spec, capacity, pixel_keys):
     """memory_efficient_replay_buffer.py:14-52: pixel leaves lose their trailing stack axis,

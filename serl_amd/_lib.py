@@ -63,6 +63,8 @@ _SIGS = {
     "serl_gather_crop_packed": [c_p, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
     "serl_gather_window": [c_p, c_ll, c_p, c_p, c_i, c_i, c_i, c_p],
     "serl_crop_offsets": [c_u, c_u, c_i, c_i, c_i, c_i, c_p, c_p],
+    "serl_prng_randint": [c_u, c_u, c_i, c_i, c_i, c_p, c_p, c_p],
+    "serl_take_rows": [c_p, c_ll, c_ll, c_p, c_p, c_i, c_p],
     "serl_prng_split": [c_u, c_u, c_i, c_p],
     "serl_prng_bits": [c_u, c_u, c_i, c_p],
     "serl_prng_choice": [c_u, c_u, c_i, c_i, c_p],

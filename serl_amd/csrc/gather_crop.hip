@@ -164,3 +164,68 @@ extern "C" int serl_crop_offsets(unsigned k0, unsigned k1, int n, int row_offset
   SERL_CHECK_LAUNCH("crop_offsets");
   return SERL_OK;
 }
+
+// Device-side index draw of Dataset.sample_jax: indx = jax.random.randint(key, (n,), minval, maxval) plus indx.max().
+// random_bits(k, (n,)) = threefry_2x32(k, arange(n)): counts are cut in halves (odd n padded with one 0), pair i is
+// (count i, count i + half) and yields elements i and i + half.
+__global__ void randint_kernel(uint32_t k0, uint32_t k1, int n, int minval, uint32_t span, int* out, int* out_max) {
+  const int half = (n + 1) / 2;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= half) return;
+  uint32_t a0, a1, b0, b1;
+  threefry_split_child(k0, k1, 2, 0, a0, a1);
+  threefry_split_child(k0, k1, 2, 1, b0, b1);
+  const bool pad = i + half >= n;
+  uint32_t h0 = (uint32_t)i, h1 = pad ? 0u : (uint32_t)(i + half), l0 = h0, l1 = h1;
+  threefry2x32(a0, a1, h0, h1);
+  threefry2x32(b0, b1, l0, l1);
+  uint32_t mult = 65536u % span;
+  mult = (mult * mult) % span;
+  const int v0 = minval + (int)(((h0 % span) * mult + (l0 % span)) % span);
+  out[i] = v0;
+  int mx = v0;
+  if (!pad) {
+    const int v1 = minval + (int)(((h1 % span) * mult + (l1 % span)) % span);
+    out[i + half] = v1;
+    mx = max(mx, v1);
+  }
+  if (out_max) atomicMax(out_max, mx);
+}
+extern "C" int serl_prng_randint(unsigned k0, unsigned k1, int n, int minval, int maxval, int* out, int* out_max,
+                                 void* stream) {
+  SERL_CHECK_ARG(out && n >= 1, "prng_randint: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  const uint32_t span = maxval > minval ? (uint32_t)((long long)maxval - minval) : 1u;
+  if (out_max) SERL_CHECK_HIP(hipMemsetD32Async((hipDeviceptr_t)out_max, (int)0x80000000, 1, st), "prng_randint");
+  hipLaunchKernelGGL(randint_kernel, dim3(cdiv((n + 1) / 2, 256)), dim3(256), 0, st, k0, k1, n, minval, span, out,
+                     out_max);
+  SERL_CHECK_LAUNCH("prng_randint");
+  return SERL_OK;
+}
+
+// jnp.take(src, indx, axis=0) on rows of row_bytes bytes (sample_jax, dataset.py:122-124): out[j] = src[indx[j]].
+template <typename T>
+__global__ __launch_bounds__(256) void take_rows_kernel(const T* src, long long nrows, long long row_elems,
+                                                        const int* indx, T* out) {
+  const int j = blockIdx.x;
+  long long r = indx[j];
+  r = r < 0 ? 0 : (r >= nrows ? nrows - 1 : r);
+  const T* s = src + r * row_elems;
+  T* d = out + (long long)j * row_elems;
+  for (long long i = blockIdx.y * 256 + threadIdx.x; i < row_elems; i += (long long)gridDim.y * 256) d[i] = s[i];
+}
+extern "C" int serl_take_rows(const void* src, long long nrows, long long row_bytes, const int* indx, void* out, int n,
+                              void* stream) {
+  SERL_CHECK_ARG(src && indx && out && n >= 1 && nrows >= 1 && row_bytes >= 1, "take_rows: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  const bool v16 = row_bytes % 16 == 0 && (((uintptr_t)src | (uintptr_t)out) & 15) == 0;
+  const bool v4 = row_bytes % 4 == 0 && (((uintptr_t)src | (uintptr_t)out) & 3) == 0;
+  const long long elems = v16 ? row_bytes / 16 : v4 ? row_bytes / 4 : row_bytes;
+  const long long gyl = cdivll(elems, 256);
+  const int gy = (int)(gyl < 64 ? gyl : 64);
+  if (v16) hipLaunchKernelGGL(take_rows_kernel<uint4>, dim3(n, gy), dim3(256), 0, st, (const uint4*)src, nrows, elems, indx, (uint4*)out);
+  else if (v4) hipLaunchKernelGGL(take_rows_kernel<uint32_t>, dim3(n, gy), dim3(256), 0, st, (const uint32_t*)src, nrows, elems, indx, (uint32_t*)out);
+  else hipLaunchKernelGGL(take_rows_kernel<unsigned char>, dim3(n, gy), dim3(256), 0, st, (const unsigned char*)src, nrows, elems, indx, (unsigned char*)out);
+  SERL_CHECK_LAUNCH("take_rows");
+  return SERL_OK;
+}

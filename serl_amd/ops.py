@@ -310,5 +310,13 @@ def gather_window(frames, cap, indx, out, n, HW3, S, stream):
     call("serl_gather_window", frames, cap, indx, out, n, HW3, S, stream)
 
 
+def prng_randint(key, n, minval, maxval, out, out_max, stream):
+    call("serl_prng_randint", int(key[0]), int(key[1]), n, minval, maxval, out, out_max, stream)
+
+
+def take_rows(src, nrows, row_bytes, indx, out, n, stream):
+    call("serl_take_rows", src, nrows, row_bytes, indx, out, n, stream)
+
+
 def crop_offsets(key, n, row_offset, n_total, pad, out, stream):
     call("serl_crop_offsets", int(key[0]), int(key[1]), n, row_offset, n_total, pad, out, stream)

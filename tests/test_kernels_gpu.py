@@ -606,3 +606,85 @@ def test_prep_weights_multi_equals_single(dev):
         assert torch.equal(wf[0], wf[1])
         if not u8:
             assert torch.equal(wd[0], wd[1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,lo,hi", [(1, 0, 7), (2, 0, 1), (9, 0, 12), (256, 3, 200000), (5121, 0, 1000000),
+                                     (4096, -5, 2**31 - 1)])
+def test_prng_randint_device_bit_exact(n, lo, hi):
+    """serl_prng_randint == oracle.prng.randint (jax.random.randint restatement), odd and even n, and the max."""
+    from oracle import prng as op
+    from serl_amd import ops
+    key = op.split(op.prng_key(n + 11))[1]
+    out = torch.empty(n + 1, dtype=torch.int32, device="cuda")
+    ops.prng_randint(key, n, lo, hi, out.data_ptr(), out.data_ptr() + 4 * n, torch.cuda.current_stream().cuda_stream)
+    ref = op.randint(key, (n,), lo, hi)
+    got = out.cpu().numpy()
+    assert np.array_equal(got[:n], ref)
+    assert got[n] == ref.max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,dtype", [((37,), np.float32), ((7,), np.uint8), ((3, 5), np.float16), ((), np.float32),
+                                          ((), np.bool_), ((16, 16, 3), np.uint8), ((1024,), np.float32)])
+def test_take_rows_bit_exact(shape, dtype):
+    from serl_amd import ops
+    rng = np.random.default_rng(0)
+    nrows, n = 101, 300
+    src = rng.integers(0, 255, size=(nrows, *shape)).astype(dtype)
+    indx = rng.integers(0, nrows, size=n).astype(np.int32)
+    indx[:3] = [0, nrows - 1, 0]
+    t = torch.from_numpy(src).cuda()
+    ix = torch.from_numpy(indx).cuda()
+    out = torch.empty((n, *shape), dtype=t.dtype, device="cuda")
+    ops.take_rows(t.data_ptr(), nrows, t[0].numel() * t.element_size(), ix.data_ptr(), out.data_ptr(), n,
+                  torch.cuda.current_stream().cuda_stream)
+    assert np.array_equal(out.cpu().numpy(), src[indx])
+
+
+@pytest.mark.gpu
+def test_gpu_replay_buffer_matches_oracle():
+    """GPUReplayBuffer.upload / insert / get_iterator (serl/data/replay_buffer.py:118-152, dataset.py:106-129)
+    against oracle.replay.ring_upload + ring_sample_jax: indices, max and every leaf bit-exact over 3 draws."""
+    from helpers import state_spaces
+    from oracle import prng as op
+    from oracle import replay as orp
+    from serl_amd.data import GPUReplayBuffer
+    obs_space, act_space = state_spaces(6, 3)
+    cap = 50
+    rb = GPUReplayBuffer(obs_space, act_space, cap)
+    ob = orp.new_ring(((6,), np.float32), ((3,), np.float32), cap)
+    rng = np.random.default_rng(1)
+
+    def blk(n):
+        return dict(observations=rng.standard_normal((n, 6)).astype(np.float32),
+                    next_observations=rng.standard_normal((n, 6)).astype(np.float32),
+                    actions=rng.standard_normal((n, 3)).astype(np.float32),
+                    rewards=rng.standard_normal(n).astype(np.float32), masks=np.ones(n, np.float32),
+                    dones=rng.integers(0, 2, n).astype(bool))
+    for n in (20, 11):
+        b = blk(n)
+        rb.upload(b)
+        orp.ring_upload(ob, b)
+    one = {k: v[0] for k, v in blk(1).items()}
+    rb.insert(one)
+    orp.ring_insert(ob, one)
+    assert len(rb) == ob["size"] == 32 and rb._insert_index == ob["head"]
+    with pytest.raises(ValueError):
+        rb.upload(blk(19))
+    with pytest.raises(NotImplementedError):
+        rb.sample(4)
+    rb.seed(7)
+    key = op.prng_key(7)
+    it = rb.get_iterator(sample_args=dict(batch_size=33))
+    for _ in range(3):
+        mx, batch = next(it)
+        key, omx, ref, indx = orp.ring_sample_jax(ob, key, 33)
+        assert int(mx) == omx
+        for k in ("observations", "next_observations", "actions", "rewards", "masks", "dones"):
+            assert np.array_equal(batch[k].cpu().numpy(), ref[k]), k
+    # default rng (no seed): PRNGKey(42), dataset.py:108
+    rb2 = GPUReplayBuffer(obs_space, act_space, cap)
+    rb2.upload(blk(10))
+    mx, batch = rb2.sample_jax(5)
+    assert int(mx) == op.randint(op.split(op.prng_key(42))[0], (5,), 0, 10).max()

@@ -130,3 +130,64 @@ def test_iterator_yields_batches_cpu():
     b1, b2 = next(it), next(it)
     assert tuple(b1["observations"][KEYS[0]].shape) == (8, 8, 16, 3, 3)
     assert b1["actions"].shape[0] == 8 and not np.array_equal(np.asarray(b1["rewards"]), np.asarray(b2["rewards"]))
+
+
+def test_dataset_split_filter_normalize():
+    """Host-side Dataset helpers (serl/data/dataset.py:131-195) against a direct restatement."""
+    from serl_amd.data import Dataset
+    rng = np.random.default_rng(5)
+    n = 57
+    dones = np.zeros(n, bool)
+    dones[[9, 20, 21, 40]] = True                      # last episode (41..56) unfinished
+    data = dict(observations=dict(state=rng.standard_normal((n, 3)).astype(np.float32)),
+                rewards=rng.standard_normal(n).astype(np.float32), dones=dones)
+    ds = Dataset({k: (dict(v) if isinstance(v, dict) else v.copy()) for k, v in data.items()}, seed=4)
+    starts, ends, rets = ds._trajectory_boundaries_and_returns()
+    assert starts == [0, 10, 21, 22, 41] and ends == [10, 21, 22, 41]
+    exp = [data["rewards"][s:e].astype(np.float64).sum() for s, e in zip(starts, ends)]
+    assert np.allclose(rets, exp, rtol=1e-5, atol=1e-6)
+    # split: the Generator's shuffle of arange(n), first int(n*ratio) rows train
+    index = np.arange(n, dtype=np.int32)
+    np.random.Generator(np.random.PCG64(np.random.SeedSequence(4))).shuffle(index)
+    tr, te = ds.split(0.7)
+    cut = int(n * 0.7)
+    assert len(tr) == cut and len(te) == n - cut
+    assert np.array_equal(tr.dataset_dict["rewards"], data["rewards"][index[:cut]])
+    assert np.array_equal(te.dataset_dict["observations"]["state"], data["observations"]["state"][index[cut:]])
+    # filter by threshold keeps whole episodes; the unfinished tail is dropped
+    thr = sorted(exp)[2]
+    keep = np.zeros(n, bool)
+    for s, e, r in zip(starts, ends, rets):
+        if r >= thr:
+            keep[s:e] = True
+    ds.filter(threshold=thr)
+    assert len(ds) == keep.sum() and np.array_equal(ds.dataset_dict["rewards"], data["rewards"][keep])
+    ds2 = Dataset({k: (dict(v) if isinstance(v, dict) else v.copy()) for k, v in data.items()})
+    ds2.filter(take_top=50)
+    thr2 = np.percentile(rets, 50)
+    assert len(ds2) == sum(e - s for s, e, r in zip(starts, ends, rets) if r >= thr2)
+    with pytest.raises(AssertionError):
+        ds2.filter()
+    ds3 = Dataset({k: (dict(v) if isinstance(v, dict) else v.copy()) for k, v in data.items()})
+    ds3.normalize_returns(scaling=10)
+    assert np.allclose(ds3.dataset_dict["rewards"], data["rewards"] / (max(rets) - min(rets)) * 10, rtol=1e-6)
+
+
+def test_oracle_sample_jax_and_upload():
+    """oracle.replay.ring_upload / ring_sample_jax: block append and the split order `key, rng = split(rng)`."""
+    from oracle import prng as op
+    ob = orp.new_ring(((4,), np.float32), ((2,), np.float32), 12)
+    rng = np.random.default_rng(2)
+    blk = lambda n: dict(observations=rng.standard_normal((n, 4)).astype(np.float32),
+                         next_observations=rng.standard_normal((n, 4)).astype(np.float32),
+                         actions=rng.standard_normal((n, 2)).astype(np.float32),
+                         rewards=np.arange(n, dtype=np.float32), masks=np.ones(n, np.float32), dones=np.zeros(n, bool))
+    orp.ring_upload(ob, blk(5))
+    orp.ring_upload(ob, blk(7))
+    assert ob["size"] == 12 and ob["head"] == 0
+    key = op.prng_key(42)
+    rng2, mx, batch, indx = orp.ring_sample_jax(ob, key, 9)
+    ks = op.split(key)
+    assert np.array_equal(rng2, ks[1]) and np.array_equal(indx, op.randint(ks[0], (9,), 0, 12))
+    assert mx == indx.max() and np.array_equal(batch["rewards"], ob["data"]["rewards"][indx])
+    assert indx.min() >= 0 and indx.max() < 12
