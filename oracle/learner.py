@@ -519,6 +519,27 @@ def drq_update(state, cfg, batch, utd_ratio, dtype=torch.float32, collect=None):
     return sac_update(new, cfg, batch, utd_ratio, dtype, collect)
 
 
+def pixel_ddpg_update(state, cfg, batch, utd_ratio, dtype=torch.float32, collect=None):
+    """serl/agents/ddpg/pixel_ddpg_learner.py:148-181.  `key, rng = split(rng)` (key first, unlike DrQ), and the
+    DDPG update runs on `new_agent`, whose rng is still the rng the call started with (:167,180)."""
+    pixel_keys = cfg["pixel_keys"]
+    if pixel_keys[0] not in batch["next_observations"]:
+        batch = unpack(batch)                                                     # :163-164
+    new = dict(state)
+    actor = dict(state["actor"])
+    actor["params"] = share_encoder(state["critic"]["params"], actor["params"])   # :166-167
+    new["actor"] = actor
+    key, rng = prng.split(new["rng"])                                             # :169
+    obs = data_augmentation(key, batch["observations"], pixel_keys)
+    key, rng = prng.split(rng)                                                    # :171
+    nxt = data_augmentation(key, batch["next_observations"], pixel_keys)
+    batch = dict(batch)
+    batch["observations"], batch["next_observations"] = obs, nxt
+    if collect is not None:
+        collect.append(dict(observations=obs, next_observations=nxt))
+    return ddpg_update(new, cfg, batch, utd_ratio, dtype, collect)                # :180 (new["rng"] untouched)
+
+
 # --------------------------------------------------------------------------- acting
 def sample_actions(state, cfg, obs, dtype=torch.float32):
     """serl/agents/agent.py:12-16,33-37 (single un-batched observation)."""

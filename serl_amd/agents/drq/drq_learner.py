@@ -36,6 +36,14 @@ class DrQLearner(SACLearner):
                critic_layer_norm: bool = False, target_entropy: Optional[float] = None,
                init_temperature: float = 1.0, backup_entropy: bool = True, pixel_keys: Tuple[str, ...] = ("pixels",),
                depth_keys: Tuple[str, ...] = (), device=None, dist=None):
+        cfg = cls._pixel_cfg(observation_space, action_space, cnn_features, cnn_filters, cnn_strides, cnn_padding,
+                             latent_dim, encoder, hidden_dims, num_qs, critic_layer_norm, pixel_keys, depth_keys)
+        return cls._build(cfg, seed, actor_lr, critic_lr, temp_lr, discount, tau, num_min_qs, critic_dropout_rate,
+                          target_entropy, init_temperature, backup_entropy, device, dist)
+
+    @staticmethod
+    def _pixel_cfg(observation_space, action_space, cnn_features, cnn_filters, cnn_strides, cnn_padding, latent_dim,
+                   encoder, hidden_dims, num_qs, critic_layer_norm, pixel_keys, depth_keys):
         if encoder != "d4pg":
             raise NotImplementedError(f"encoder={encoder!r}: only the d4pg conv encoder is on the hot path")
         if cnn_padding != "VALID":
@@ -51,13 +59,11 @@ class DrQLearner(SACLearner):
         extra = set(observation_space.spaces) - set(pixel_keys) - {"state"}
         if extra:
             raise NotImplementedError(f"unsupported extra observation keys {sorted(extra)}")
-        cfg = NetConfig(action_dim=int(action_space.shape[-1]), hidden_dims=tuple(int(h) for h in hidden_dims),
+        return NetConfig(action_dim=int(action_space.shape[-1]), hidden_dims=tuple(int(h) for h in hidden_dims),
                         num_qs=int(num_qs), critic_layer_norm=bool(critic_layer_norm), pixel_keys=pixel_keys,
                         state_dim=int(observation_space.spaces["state"].shape[-1]), H=int(H), W=int(W), stack=int(S),
                         cnn_features=tuple(cnn_features), cnn_filters=tuple(cnn_filters),
                         cnn_strides=tuple(cnn_strides), latent_dim=int(latent_dim))
-        return cls._build(cfg, seed, actor_lr, critic_lr, temp_lr, discount, tau, num_min_qs, critic_dropout_rate,
-                          target_entropy, init_temperature, backup_entropy, device, dist)
 
     # ------------------------------------------------------------------ augmentation + unpack + gather
     def _augment(self, batch, n, key_obs, key_next, ws):
@@ -157,6 +163,13 @@ class DrQLearner(SACLearner):
             nn.encoder_bwd(cfg, tag, store, grads, imgs, B, ws, st, gside=gside, use_masks=True)
 
     # ------------------------------------------------------------------ update
+    def _aug_keys(self):
+        """(key for obs, key for next_obs, rng the SAC update starts from).
+        rng, key = split(rng) -- note: rng is child 0 here (drq_learner.py:174,176)."""
+        rng, key_obs = prng.split(self.rng)
+        rng, key_next = prng.split(rng)
+        return key_obs, key_next, rng
+
     def update(self, batch, utd_ratio: int, pixel_keys=("pixels",)):
         cfg = self._cfg
         pixel_keys = tuple(pixel_keys)
@@ -172,9 +185,7 @@ class DrQLearner(SACLearner):
         actor = self.actor.clone()
         nenc = self.critic.store.layout.prefix_size("image_encoder")
         actor.store.flat[:nenc].copy_(self.critic.store.flat[:nenc])
-        # rng, key = split(rng) -- note: rng is child 0 here (drq_learner.py:174,176)
-        rng, key_obs = prng.split(self.rng)
-        rng, key_next = prng.split(rng)
+        key_obs, key_next, rng = self._aug_keys()
         aug, crop = self._augment(batch, n, key_obs, key_next, ws)
         feats = dict(aug=aug, crop=crop,
                      state=_to_dev(batch["observations"]["state"], dev, f32).reshape(n, cfg.state_dim),

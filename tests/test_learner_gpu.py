@@ -314,6 +314,42 @@ def test_ddpg_learner_matches_oracle(dev, layer_norm, prec):
     assert np.allclose(agent.eval_actions(ob), ol.eval_actions(osync, ocfg, ob), atol=5e-4)
 
 
+@pytest.mark.parametrize("packed", [True, False])
+def test_pixel_ddpg_learner_matches_oracle(dev, packed, prec):
+    """PixelDDPGLearner (serl/agents/ddpg/pixel_ddpg_learner.py:148-181): DrQ's augmentation with `key, rng = split`
+    key order, the rng NOT advanced by the augmentation splits, then the DDPG update (1 critic, 3 info keys)."""
+    from oracle import learner as ol
+    from serl_amd.agents import PixelDDPGLearner
+    keys = ("wrist_1", "wrist_2")
+    H = W = 32; S = 2; B, U = 6, 2
+    obs_space, act_space = pixel_spaces(keys, H, W, S, 19, 7)
+    agent = PixelDDPGLearner.create(5, obs_space, act_space, pixel_keys=keys, critic_layer_norm=True)
+    assert agent.num_qs == 1
+    rng = np.random.default_rng(3)
+    for it in range(2):
+        ostate, ocfg = agent_to_oracle(agent)
+        ocfg.update(num_qs=1, num_min_qs=1, backup_entropy=False)
+        batch = make_pixel_batch(rng, B * U, keys, H, W, S, 19, 7, packed=packed)
+        collect = []
+        ostate, oinfo = ol.pixel_ddpg_update(ostate, ocfg, batch, U, collect=collect)
+        agent, info = agent.update(batch, U, pixel_keys=keys)
+        ws = agent._ws(B)
+        for side, okey in (("obs", "observations"), ("next", "next_observations")):
+            for cam in keys:
+                got = ws.tensor(f"aug_{side}_{cam}", (B * U, H, W, 3 * S), torch.uint8).cpu().numpy()
+                assert np.array_equal(got.reshape(B * U, H, W, 3, S), collect[0][okey][cam]), f"aug {side} {cam}"
+        assert list(info) == ["actor_loss", "critic_loss", "q"]
+        assert_info_close(info, oinfo, rtol=1e-3 if prec == "highest" else 5e-3)
+        assert np.array_equal(agent.rng, ostate["rng"])
+    _check_params(agent, ostate, 3e-4, U)
+    ob = {k: rng.integers(0, 256, size=(H, W, 3, S), dtype=np.uint8) for k in keys}
+    ob["state"] = rng.standard_normal(19).astype(np.float32)
+    osync, ocfg = agent_to_oracle(agent)
+    a, agent2 = agent.sample_actions(ob)
+    oa, osync2 = ol.ddpg_sample_actions(osync, ocfg, ob)
+    assert np.allclose(a, oa, atol=5e-4) and np.array_equal(agent2.rng, osync2["rng"])
+
+
 @pytest.mark.parametrize("repeat", [0, 1, 2])
 def test_learner_thread_and_acting_thread(dev, repeat):
     """The reference's threading pattern (serl_examples/*: learner_thread + main loop): one thread calls update()
