@@ -447,20 +447,45 @@ typedef TileCfg<128, 64, 64, 4, 2> S128x64k64;      // 8 waves
 typedef TileCfg<128, 64, 32, 4, 2> S128x64k32;
 typedef TileCfg<128, 32, 64, 4, 1> S128x32k64;
 typedef TileCfg<128, 32, 32, 4, 1> S128x32k32;
+// 256-row forward tiles for the first two layers (two 32-row MFMA tiles per wave): half the blocks, the per-block
+// prologue (row contexts, weight tile) amortised over twice the output; measured +1.7 % on the whole update
+// (tools/ab_tiles.sh); 512 rows, 256-row data-gradient tiles and 256 x 128 tiles for layers 3-4 measured slower.
+typedef TileCfg<256, 64, 32, 4, 2> S256x64k32;      // 8 waves
+typedef TileCfg<256, 32, 32, 4, 1> S256x32k32;
 
+#ifndef S_FWD32
+#define S_FWD32 S256x32k32
+#endif
+#ifndef S_FWD64
+#define S_FWD64 S256x64k32
+#endif
+#ifndef S_DG32
+#define S_DG32 S128x32k64
+#endif
+#ifndef S_DG64
+#define S_DG64 S128x64k64
+#endif
+#ifndef S_BIG
+#define S_BIG S128x128k64
+#endif
 enum SKind { S_FWD, S_DGRAD, S_WGRAD };
 template <class P>
 static int s_launch_by_n(SKind kind, const P& p, int max_m, int n, int nsplit, int nz, hipStream_t st, const char* name) {
+  const bool big_m = (long long)cdiv(max_m, 256) * nz >= 512;   // 256-row tiles only when they still fill the chip twice
   if (n <= 32) {
+    if (kind == S_FWD && big_m) return sgemm_launch<P, S_FWD32, 1>(p, max_m, n, nsplit, nz, st, name);
     if (kind == S_FWD) return sgemm_launch<P, S128x32k32, 1>(p, max_m, n, nsplit, nz, st, name);
+    if (kind == S_DGRAD) return sgemm_launch<P, S_DG32, 1>(p, max_m, n, nsplit, nz, st, name);
     return sgemm_launch<P, S128x32k64, 1>(p, max_m, n, nsplit, nz, st, name);
   }
   if (n <= 64) {
+    if (kind == S_FWD && big_m) return sgemm_launch<P, S_FWD64, 1>(p, max_m, n, nsplit, nz, st, name);
     if (kind == S_FWD) return sgemm_launch<P, S128x64k32, 1>(p, max_m, n, nsplit, nz, st, name);
+    if (kind == S_DGRAD) return sgemm_launch<P, S_DG64, 1>(p, max_m, n, nsplit, nz, st, name);
     return sgemm_launch<P, S128x64k64, 1>(p, max_m, n, nsplit, nz, st, name);
   }
   if (kind == S_WGRAD) return sgemm_launch<P, S128x128k32, 2>(p, max_m, n, nsplit, nz, st, name);
-  return sgemm_launch<P, S128x128k64, 1>(p, max_m, n, nsplit, nz, st, name);
+  return sgemm_launch<P, S_BIG, 1>(p, max_m, n, nsplit, nz, st, name);
 }
 
 static bool all_aligned16(const void* const* ps, int n) {
