@@ -468,6 +468,23 @@ typedef TileCfg<256, 32, 32, 4, 1> S256x32k32;
 #ifndef S_BIG
 #define S_BIG S128x128k64
 #endif
+#ifndef S_WG32
+#define S_WG32 S128x32k64
+#endif
+// Weight-gradient tiles: 32-deep K slabs in one LDS stage.  Stand-alone the 64-deep / two-stage tiles are a few
+// percent faster, but the weight gradients run on the side stream next to the data gradients: the smaller LDS
+// footprint lets both kernels' blocks share a CU (+1.9 % on the whole update, tools/ab_tiles.sh).
+#ifndef S_WG64
+#define S_WG64 S128x64k32
+#endif
+#ifndef S_WG64_LBUF
+#define S_WG64_LBUF 1
+#endif
+typedef TileCfg<128, 128, 32, 4, 2> S128x128k32w8;   // 8 waves
+#ifndef S_WGBIG
+#define S_WGBIG S128x128k32w8
+#define S_WGBIG_LBUF 1
+#endif
 enum SKind { S_FWD, S_DGRAD, S_WGRAD };
 template <class P>
 static int s_launch_by_n(SKind kind, const P& p, int max_m, int n, int nsplit, int nz, hipStream_t st, const char* name) {
@@ -476,15 +493,15 @@ static int s_launch_by_n(SKind kind, const P& p, int max_m, int n, int nsplit, i
     if (kind == S_FWD && big_m) return sgemm_launch<P, S_FWD32, 1>(p, max_m, n, nsplit, nz, st, name);
     if (kind == S_FWD) return sgemm_launch<P, S128x32k32, 1>(p, max_m, n, nsplit, nz, st, name);
     if (kind == S_DGRAD) return sgemm_launch<P, S_DG32, 1>(p, max_m, n, nsplit, nz, st, name);
-    return sgemm_launch<P, S128x32k64, 1>(p, max_m, n, nsplit, nz, st, name);
+    return sgemm_launch<P, S_WG32, 1>(p, max_m, n, nsplit, nz, st, name);
   }
   if (n <= 64) {
     if (kind == S_FWD && big_m) return sgemm_launch<P, S_FWD64, 1>(p, max_m, n, nsplit, nz, st, name);
     if (kind == S_FWD) return sgemm_launch<P, S128x64k32, 1>(p, max_m, n, nsplit, nz, st, name);
     if (kind == S_DGRAD) return sgemm_launch<P, S_DG64, 1>(p, max_m, n, nsplit, nz, st, name);
-    return sgemm_launch<P, S128x64k64, 1>(p, max_m, n, nsplit, nz, st, name);
+    return sgemm_launch<P, S_WG64, S_WG64_LBUF>(p, max_m, n, nsplit, nz, st, name);
   }
-  if (kind == S_WGRAD) return sgemm_launch<P, S128x128k32, 2>(p, max_m, n, nsplit, nz, st, name);
+  if (kind == S_WGRAD) return sgemm_launch<P, S_WGBIG, S_WGBIG_LBUF>(p, max_m, n, nsplit, nz, st, name);
   return sgemm_launch<P, S_BIG, 1>(p, max_m, n, nsplit, nz, st, name);
 }
 
