@@ -485,6 +485,9 @@ typedef TileCfg<128, 128, 32, 4, 2> S128x128k32w8;   // 8 waves
 #define S_WGBIG S128x128k32w8
 #define S_WGBIG_LBUF 1
 #endif
+#ifndef S_DGBIG
+#define S_DGBIG S128x128k32   // last layer's data gradient: 32-deep slab (+0.5 % next to the weight gradient; 64-deep stand-alone)
+#endif
 enum SKind { S_FWD, S_DGRAD, S_WGRAD };
 template <class P>
 static int s_launch_by_n(SKind kind, const P& p, int max_m, int n, int nsplit, int nz, hipStream_t st, const char* name) {
@@ -502,6 +505,7 @@ static int s_launch_by_n(SKind kind, const P& p, int max_m, int n, int nsplit, i
     return sgemm_launch<P, S_WG64, S_WG64_LBUF>(p, max_m, n, nsplit, nz, st, name);
   }
   if (kind == S_WGRAD) return sgemm_launch<P, S_WGBIG, S_WGBIG_LBUF>(p, max_m, n, nsplit, nz, st, name);
+  if (kind == S_DGRAD) return sgemm_launch<P, S_DGBIG, 1>(p, max_m, n, nsplit, nz, st, name);
   return sgemm_launch<P, S_BIG, 1>(p, max_m, n, nsplit, nz, st, name);
 }
 
