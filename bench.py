@@ -7,8 +7,11 @@ indices, states, actions) are resident in HBM when the timed region starts.
 `value` = grad-steps/s x (global_batch / 256): at N GPUs every rank keeps batch 256 (weak scaling, one RCCL
 gradient all-reduce per critic step), so value = batch-256-equivalent grad-steps/s of the whole job.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--no-cpu-baseline]
-N > 1 is launched by torch.distributed.run, one rank per GPU.
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--global-batch G] [--no-cpu-baseline]
+N > 1: one rank per GPU.  Under torch.distributed.run (WORLD_SIZE set) this process is one of the ranks; started
+plainly (`python bench.py --gpus N`) it starts the N ranks itself as children of `python -m torch.distributed.run`,
+BEFORE anything touches the GPU, relays rank 0's JSON line and exits with the children's return code.
+`--global-batch G` (BASELINE config 5: 4096 / 8192) gives every rank G/N rows per critic step (strong scaling).
 """
 import argparse
 import json
@@ -59,9 +62,11 @@ def measured_traffic(key):
     return (e["hbm_side_bytes"], os.path.basename(files[-1])) if e else (None, None)
 
 
-def cpu_baseline(seed=0):
-    """CPU restatement (oracle, torch-CPU fp32 -- NOT JAX/XLA) on a bounded sample of the same workload:
-    one update() call with UTD 16 at batch 256 (16 grad-steps + the actor/temperature step), ~10-20 s."""
+def cpu_baseline(seed=0, progress=lambda m: None):
+    """CPU restatement (oracle, torch-CPU fp32 -- NOT JAX/XLA) on a bounded sample of the same workload, BASELINE.md
+    section 3's protocol cut to the bench's time budget: update() calls at UTD 20, batch 256 (20 grad-steps + the
+    actor/temperature step each), one un-timed warm-up call at UTD 2 (thread pool, allocator), then the median of 3
+    timed calls (the protocol asks for >= 5 after 2 warm-ups: ~15 s per call on 16 threads makes that > 100 s)."""
     import torch
     from helpers import agent_to_oracle, make_pixel_batch, pixel_spaces
     from oracle import learner as ol
@@ -69,14 +74,48 @@ def cpu_baseline(seed=0):
     obs_space, act_space = pixel_spaces(KEYS, H, W, STACK, STATE_DIM, ACT_DIM)
     agent = DrQLearner.create(seed, obs_space, act_space, pixel_keys=KEYS, **AGENT_KW)
     ostate, ocfg = agent_to_oracle(agent)
-    u = 16
-    batch = make_pixel_batch(np.random.default_rng(seed), BATCH * u, KEYS, H, W, STACK, STATE_DIM, ACT_DIM, packed=True)
-    t0 = time.perf_counter()
-    ol.drq_update(ostate, ocfg, batch, u)
-    dt = time.perf_counter() - t0
+    u, ncalls = 20, 3
+    rng = np.random.default_rng(seed)
+    warm = make_pixel_batch(rng, 256 * 2, KEYS, H, W, STACK, STATE_DIM, ACT_DIM, packed=True)
+    ostate, _ = ol.drq_update(ostate, ocfg, warm, 2)
+    batch = make_pixel_batch(rng, 256 * u, KEYS, H, W, STACK, STATE_DIM, ACT_DIM, packed=True)
+    times = []
+    for _ in range(ncalls):
+        t0 = time.perf_counter()
+        ostate, _ = ol.drq_update(ostate, ocfg, batch, u)
+        times.append(time.perf_counter() - t0)
+        progress(f"  cpu call {len(times)}/{ncalls}: {times[-1]:.1f} s")
+    dt = float(np.median(times))
     return {"value": u / dt, "unit": "grad-steps/s", "cores": int(torch.get_num_threads()), "kind": "port",
-            "sample": f"1 update() call, UTD {u}, batch {BATCH} ({u} grad-steps + actor step), {dt:.1f} s; "
+            "sample": f"median of {ncalls} update() calls at UTD {u}, batch 256 ({u} grad-steps + actor step each; "
+                      f"{', '.join(f'{t:.1f}' for t in times)} s) after one warm-up call at UTD 2; "
                       "CPU restatement (torch-CPU fp32), not JAX/XLA"}
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as children (torch.distributed.run, rendezvous
+    on 127.0.0.1) before this process imports torch or touches the GPU; relay rank 0's JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line)
+    elif proc.returncode == 0:
+        print("bench.py: the ranks exited without a result line", file=sys.stderr)
+        return 1
+    return proc.returncode
 
 
 def main():
@@ -89,13 +128,23 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="per-GPU minibatch (default 256 = the headline config; "
                     "other values are SURVEY 8d's large-batch variants and are labelled as such)")
     ap.add_argument("--utd", type=int, default=None, help="UTD ratio (default 20 = the headline config)")
+    ap.add_argument("--global-batch", type=int, default=None,
+                    help="rows per critic step over ALL ranks (BASELINE config 5: 4096 / 8192): every rank takes "
+                         "global_batch / gpus rows (strong scaling); default: 256 rows per rank (weak scaling)")
+    ap.add_argument("--no-highest", action="store_true", help="skip the extra timed steps at precision 'highest'")
     ap.add_argument("--phases", action="store_true",
                     help="after the timed region, one more update() with HIP-event marks between its phases (stderr)")
     ap.add_argument("--precision", default="bf16_3x", choices=["bf16_3x", "highest"],
                     help="serl_amd.set_matmul_precision: bf16_3x (default of the library) or highest (exact fp32 MFMA)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))       # nothing has touched the GPU (torch is not even imported)
     global BATCH, UTD
-    headline = (args.batch in (None, 256)) and (args.utd in (None, 20))
+    if args.global_batch is not None:
+        assert args.batch is None, "--batch (rows per rank) and --global-batch (rows over all ranks) exclude each other"
+        assert args.global_batch % args.gpus == 0, "--global-batch must be divisible by --gpus"
+        args.batch = args.global_batch // args.gpus
+    headline = (args.batch in (None, 256)) and (args.utd in (None, 20)) and args.global_batch is None
     BATCH, UTD = args.batch or BATCH, args.utd or UTD
 
     import torch
@@ -114,6 +163,7 @@ def main():
     rehearsal = os.environ.get("SERL_AMD_BENCH_REHEARSAL", "0") != "0"
     if rehearsal:
         local_rank = 0
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
@@ -124,10 +174,16 @@ def main():
         else:
             td.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         dist = DataParallel()
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    t_start = time.perf_counter()
+
+    def progress(msg):          # stderr, rank 0: a line per phase so that a long run never looks hung
+        if rank == 0:
+            print(f"[bench +{time.perf_counter() - t_start:6.1f}s] {msg}", file=sys.stderr, flush=True)
 
     obs_space, act_space = pixel_spaces(KEYS, H, W, STACK, STATE_DIM, ACT_DIM)
     agent = DrQLearner.create(42, obs_space, act_space, pixel_keys=KEYS, dist=dist, **AGENT_KW)
+    progress(f"agent created (world {world}, batch {BATCH}/gpu, utd {UTD}, precision {precision})")
     # online buffer + demo prefix: 50/50 demo/online mixing via the tail-overwrite rule
     buf = MemoryEfficientReplayBuffer(obs_space, act_space, 6000, pixel_keys=KEYS, device="cuda")
     fill_buffer(buf, 4000, seed=rank)
@@ -145,8 +201,11 @@ def main():
             td.barrier()
         torch.cuda.synchronize()
 
+    progress("buffer filled, batches sampled")
     for b in batches[:args.warmup]:
         agent, info = agent.update(b, UTD, pixel_keys=KEYS)
+    torch.cuda.synchronize()
+    progress("warm-up done")
     timer = None
     if not args.no_kernel_timer:
         timer = ops.TIMER = ops.KernelTimer()
@@ -158,14 +217,17 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     ops.TIMER = None
+    progress(f"timed region done: {elapsed / args.steps * 1e3:.2f} ms/step")
     # end to end: the same loop with the host-side index draw, rejection resampling and H2D of the small leaves inside
     # it (the iterator samples batch i+1 while the GPU runs update i: update() does not block the host)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        agent, info = agent.update(next(it), UTD, pixel_keys=KEYS)
-    barrier()
-    e2e = time.perf_counter() - t0
+    e2e = float("nan")
+    if not rehearsal:       # (the one-GPU gloo rehearsal needs seconds per all-reduce: it runs the timed region only)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            agent, info = agent.update(next(it), UTD, pixel_keys=KEYS)
+        barrier()
+        e2e = time.perf_counter() - t0
     if args.phases and rank == 0:
         ops.PHASES = marks = []
         agent.update(batches[-1], UTD, pixel_keys=KEYS)
@@ -178,10 +240,32 @@ def main():
             print(f"phase {k:28s} n={len(v):3d} mean {sum(v) / len(v) * 1e3:8.1f} us  total {sum(v):7.2f} ms",
                   file=sys.stderr)
     if dist is not None:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         import torch.distributed as td
+        t = torch.tensor([elapsed, e2e], device="cuda", dtype=torch.float64)
         td.all_reduce(t, op=td.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, e2e = float(t[0].item()), float(t[1].item())
+
+    # the same steps at precision "highest" (exact fp32 MFMA: the precision at which north_star's free-running
+    # rel-1e-3 tolerance holds), timed by this run so that the figure is not only the builder's
+    progress("end-to-end loop done")
+    highest_value = None
+    if precision != "highest" and not args.no_highest and not rehearsal:
+        serl_amd.set_matmul_precision("highest")
+        hb = batches[-min(3, len(batches)):]
+        agent_h, _ = agent.update(hb[0], UTD, pixel_keys=KEYS)        # warm-up: fp32 workspaces
+        barrier()
+        t0 = time.perf_counter()
+        for b in hb:
+            agent_h, _ = agent_h.update(b, UTD, pixel_keys=KEYS)
+        barrier()
+        th = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([th], device="cuda", dtype=torch.float64)
+            td.all_reduce(t, op=td.ReduceOp.MAX)
+            th = float(t.item())
+        highest_value = len(hb) * UTD * world / th * (BATCH / 256.0)
+        serl_amd.set_matmul_precision(precision)
+        progress("precision 'highest' steps done")
 
     grad_steps = args.steps * UTD
     value = grad_steps * world / elapsed * (BATCH / 256.0)
@@ -233,23 +317,30 @@ def main():
                                  dict(roof(v), launches=v[0], avg_ms=round(v[1], 4),
                                       tflops=round(v[2] / (v[1] * 1e-3) / 1e12, 2),
                                       gbs=round(v[3] / (v[1] * 1e-3) / 1e9, 1)) for k, v in summ.items()}})
+    gb = BATCH * world
     out = {
         "metric": "learner grad-steps/sec, DrQ-RLPD 128^2 pixels, batch 256, 10 critics, UTD 20" if headline else
-                  f"NOT THE HEADLINE CONFIG: grad-steps/sec x batch/256, batch {BATCH}, UTD {UTD}",
+                  f"grad-steps/sec x global_batch/256 (BASELINE config 5 family, NOT the headline config): DrQ-RLPD "
+                  f"128^2 pixels, global batch {gb}, 10 critics, UTD {UTD}",
         "value": round(value, 3), "unit": "grad-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+        "scaling": "strong" if args.global_batch is not None else "weak",
         "vs_baseline": None, "dtype": "f32" if precision == "highest" else "bf16_3x", "data": "synthetic",
-        "config": {"workload": "DrQ-RLPD update(): 2 cams 128x128x3 uint8, frame stack 3, conv encoder 32-64-128-256 "
-                               "stride 2, 10 LayerNorm critics / 2 subsampled targets, UTD 20, 50/50 demo tail mixing, "
-                               "HBM-resident MemoryEfficientReplayBuffer",
-                   "batch_per_gpu": BATCH, "global_batch": BATCH * world, "utd": UTD,
-                   "step_definition": "1 step = 1 update() call = 20 critic grad-steps + 1 actor/temperature step",
-                   "value_definition": "grad-steps/s x global_batch/256", "parallelism": f"dp{world}"},
+        "config": {"workload": f"DrQ-RLPD update(): 2 cams 128x128x3 uint8, frame stack 3, conv encoder 32-64-128-256 "
+                               f"stride 2, 10 LayerNorm critics / 2 subsampled targets, UTD {UTD}, batch {BATCH} per "
+                               f"GPU, 50/50 demo tail mixing, HBM-resident MemoryEfficientReplayBuffer",
+                   "batch_per_gpu": BATCH, "global_batch": gb, "utd": UTD,
+                   "step_definition": f"1 step = 1 update() call = {UTD} critic grad-steps of {gb} rows + 1 "
+                                      f"actor/temperature step",
+                   "value_definition": "critic grad-steps/s x global_batch/256 (256-row grad-step equivalents)",
+                   "parallelism": f"dp{world}"},
         "matmul_precision": precision,
         "model_tflops": round(value * FLOP_PER_GRAD_STEP / 1e12, 2),
+        "highest_value": None if highest_value is None else round(highest_value, 3),
+        "highest_note": "the same update() calls at precision 'highest' (exact fp32 MFMA), 3 timed steps in this run",
         "host_index_sampling_ms_per_update": round(sample_ms, 2),
         "host_enqueue_ms_per_step": round(host_enqueue / args.steps * 1e3, 2),
-        "end_to_end_value": round(args.steps * UTD * world / e2e * (BATCH / 256.0), 3),
+        "end_to_end_value": None if rehearsal else round(args.steps * UTD * world / e2e * (BATCH / 256.0), 3),
         "end_to_end_note": "same steps with buffer.sample (index draw + rejection + H2D of state/action leaves) inside "
                            "the loop; frames stay in HBM",
         "last_info": {k: round(float(v), 5) for k, v in info.items()},
@@ -257,7 +348,8 @@ def main():
     if roofline is not None:
         out["roofline"] = roofline
     if rank == 0 and world == 1 and not args.no_cpu_baseline and headline:
-        out["cpu_baseline"] = cpu_baseline()
+        progress("CPU baseline (oracle on the host cores, ~60 s) ...")
+        out["cpu_baseline"] = cpu_baseline(progress=progress)
         out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
     if rank == 0:
         print(json.dumps(out))

@@ -72,6 +72,16 @@ int serl_convs_dgrad(int ngroups, const void* const* dz, const void* const* wd, 
 int serl_convs_wgrad(int ngroups, const void* const* x, const void* const* dz, float* const* dw, float* const* dbias,
                      float* workspace, long long workspace_bytes, int in_u8, int B, int IH, int IW, int C, int KH,
                      int KW, int stride, int F, void* stream);
+/* serl_convs_wgrad without a workspace argument and without any allocation.  NO COUNTERPART IN THE REFERENCE: it is for
+ * callers that cannot call hipMalloc -- code under HIP graph capture, tight serving loops, harnesses that forbid it.
+ * The split-K slabs live in a 64 MiB file-scope device array of the library (one copy per GPU, held until the process
+ * ends); shapes whose slabs need more (serl_conv2d_wgrad_workspace_bytes > serl_convs_wgrad_noalloc_max_bytes) are
+ * rejected with status 1.  Results are bit-identical to serl_convs_wgrad.  All calls on one GPU share the array: calls
+ * that overlap in time on one GPU (different streams or threads) race. */
+long long serl_convs_wgrad_noalloc_max_bytes(void);
+int serl_convs_wgrad_noalloc(int ngroups, const void* const* x, const void* const* dz, float* const* dw,
+                             float* const* dbias, int in_u8, int B, int IH, int IW, int C, int KH, int KW, int stride,
+                             int F, void* stream);
 
 /* ---- SpatialLearnedEmbeddings, serl/networks/spatial.py:13-27 (F must be 8) */
 int serl_sle_fwd(int ngroups, const void* const* feat, const float* const* ker, float* const* out, int ldo, int B,

@@ -33,9 +33,12 @@ _ROT = ((13, 15, 26, 6), (17, 29, 16, 24))
 
 
 def prng_key(seed: int) -> np.ndarray:
-    """jax.random.PRNGKey(seed) -> uint32[2] = [hi, lo]."""
-    seed = int(seed) & 0xFFFFFFFFFFFFFFFF
-    return np.array([seed >> 32, seed & 0xFFFFFFFF], dtype=U32)
+    """jax.random.PRNGKey(seed) -> uint32[2] = [hi, lo].  With jax_enable_x64 off (the reference never turns it on) the
+    seed is an int32: the logical right shift by 32 gives hi = 0 also for negative seeds (recalled from jax/_src/prng.py
+    threefry_seed; parity unpinned), lo = the two's-complement low word."""
+    seed = int(seed)
+    hi = (seed >> 32) & 0xFFFFFFFF if seed >= 0 else 0
+    return np.array([hi, seed & 0xFFFFFFFF], dtype=U32)
 
 
 def _rotl(x, r):

@@ -59,6 +59,8 @@ _SIGS = {
     "serl_convs_fwd": [c_i, PP, PP, PP, PP, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, PP, c_p],
     "serl_convs_dgrad": [c_i, PP, PP, PP, PP, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "serl_convs_wgrad": [c_i, PP, PP, PP, PP, c_p, c_ll, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
+    "serl_convs_wgrad_noalloc": [c_i, PP, PP, PP, PP, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
+    "serl_convs_wgrad_noalloc_max_bytes": [],
     "serl_gather_crop_frames": [c_p, c_ll, c_p, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
     "serl_gather_crop_packed": [c_p, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
     "serl_gather_window": [c_p, c_ll, c_p, c_p, c_i, c_i, c_i, c_p],
@@ -69,7 +71,8 @@ _SIGS = {
     "serl_prng_bits": [c_u, c_u, c_i, c_p],
     "serl_prng_choice": [c_u, c_u, c_i, c_i, c_p],
 }
-_RESTYPE = {"serl_conv2d_wgrad_workspace_bytes": c_ll, "serl_convs_weight_bytes": c_ll}
+_RESTYPE = {"serl_conv2d_wgrad_workspace_bytes": c_ll, "serl_convs_weight_bytes": c_ll,
+            "serl_convs_wgrad_noalloc_max_bytes": c_ll}
 
 EXPORTS = tuple(_SIGS) + ("serl_last_error",)
 

@@ -66,7 +66,7 @@ class DrQLearner(SACLearner):
                         cnn_strides=tuple(cnn_strides), latent_dim=int(latent_dim))
 
     # ------------------------------------------------------------------ augmentation + unpack + gather
-    def _augment(self, batch, n, key_obs, key_next, ws):
+    def _augment(self, batch, n, utd_ratio, key_obs, key_next, ws):
         """Returns ({'obs'|'next': [u8 (n,H,W,3S) device tensor per camera in cfg.cams order]}, crop) where
         crop(lo, rows, stream) launches the fused gather + _unpack + random-shift kernels for rows [lo, lo+rows)
         of every (side, camera); the per-row offsets are computed here, for all rows.
@@ -79,7 +79,7 @@ class DrQLearner(SACLearner):
         world = dist.world_size if dist is not None else 1
         rank = dist.rank if dist is not None else 0
         out = {"obs": {}, "next": {}}
-        jobs = []
+        jobs, lazy = [], []
         obs, nxt = batch["observations"], batch["next_observations"]
         img = H * W * 3 * S
         for side, rng, t0 in (("obs", key_obs, 0), ("next", key_next, 1)):
@@ -89,7 +89,7 @@ class DrQLearner(SACLearner):
                 if world == 1:
                     ops.crop_offsets(key, n, 0, n, PAD, off.data_ptr(), st)
                 else:                                                    # global-index keyed
-                    U = self._utd
+                    U = utd_ratio
                     B = n // U
                     for i in range(U):
                         ops.crop_offsets(key, B, i * B * world + rank * B, n * world, PAD,
@@ -97,7 +97,11 @@ class DrQLearner(SACLearner):
                 dst = ws.tensor(f"aug_{side}_{cam}", (n, H, W, 3 * S), torch.uint8)
                 packed = cam not in nxt
                 src = obs[cam] if (side == "obs" or packed) else nxt[cam]
+                if isinstance(src, FrameWindows) and src.packed is not None:
+                    src = src.packed              # an insert() hit this batch's rows before the gather: snapshot taken then
                 if isinstance(src, FrameWindows):
+                    lazy.append(src)
+
                     def job(lo, rows, stream, src=src, off=off, dst=dst, t0=t0):
                         ops.gather_crop_frames(src.frames.data_ptr(), src.capacity, src.indx.data_ptr() + 8 * lo, S + 1,
                                                t0, off.data_ptr() + 8 * lo, dst.data_ptr() + lo * img, rows, H, W, S,
@@ -121,6 +125,9 @@ class DrQLearner(SACLearner):
         def crop(lo, rows, stream):
             for job in jobs:
                 job(lo, rows, stream)
+            if lo + rows >= n:       # every row's gather is enqueued: later inserts are ordered behind it by the stream
+                for fw in lazy:
+                    fw.consumed = True
         return out, crop
 
     def _prepare(self, batch, n):
@@ -148,15 +155,13 @@ class DrQLearner(SACLearner):
                          save=(tag == save_tag))
 
     def _features_bwd(self, tag, store, grads, feats, lo, B, ws, st, dz_ptr, lddz, need_encoder, gside=None,
-                      on_head_grads=None, dz_slabs=(1, 0)):
+                      dz_slabs=(1, 0)):
         cfg = self._cfg
         ldz = cfg.latent + cfg.action_dim
         which = "obs"
         state = feats["state"]
         nn.trunk_bwd(cfg, tag, store, grads, state.data_ptr() + 4 * lo * cfg.state_dim, ws.ptr(f"z{tag}", (B, ldz)),
                      ldz, dz_ptr, lddz, B, ws, st, need_denc=need_encoder, gside=gside, dz_slabs=dz_slabs)
-        if on_head_grads is not None:      # every gradient leaf outside image_encoder/* is enqueued now
-            on_head_grads()
         if need_encoder:
             img_bytes = cfg.H * cfg.W * 3 * cfg.stack
             imgs = [feats["aug"][which][cam].data_ptr() + lo * img_bytes for cam in cfg.cams]
@@ -179,14 +184,13 @@ class DrQLearner(SACLearner):
         assert n % utd_ratio == 0
         dev = self.actor.store.flat.device
         f32 = torch.float32
-        self._utd = utd_ratio
         ws = self._ws(n // utd_ratio)
         # share the critic's encoder with the actor, once per call (drq_learner.py:171-172)
         actor = self.actor.clone()
         nenc = self.critic.store.layout.prefix_size("image_encoder")
         actor.store.flat[:nenc].copy_(self.critic.store.flat[:nenc])
         key_obs, key_next, rng = self._aug_keys()
-        aug, crop = self._augment(batch, n, key_obs, key_next, ws)
+        aug, crop = self._augment(batch, n, utd_ratio, key_obs, key_next, ws)
         feats = dict(aug=aug, crop=crop,
                      state=_to_dev(batch["observations"]["state"], dev, f32).reshape(n, cfg.state_dim),
                      next_state=_to_dev(batch["next_observations"]["state"], dev, f32).reshape(n, cfg.state_dim))

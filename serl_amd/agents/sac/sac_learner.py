@@ -24,19 +24,6 @@ from ...networks.modules import Workspace
 from ...networks.params import ParamStore
 from ...networks.spec import NetConfig, actor_layout, critic_head_prefix, critic_layout, init_tree
 from ..agent import Agent
-import os
-
-# the actor's no-grad pass over next_obs (constant parameters during a call) runs ahead on its own stream
-ACTOR_RUNAHEAD = os.environ.get("SERL_AMD_ACTOR_RUNAHEAD", "1") != "0"
-# augment minibatch j+1 on the run-ahead stream during critic step j instead of all rows up front: measured neutral
-# (the idle windows are already full with the actor pass), off by default
-CHUNKED_CROP = os.environ.get("SERL_AMD_CHUNKED_CROP", "0") != "0"
-ACTOR_GATE = os.environ.get("SERL_AMD_ACTOR_GATE", "1") != "0"
-# all-reduce of the head/trunk gradient leaves issued asynchronously and overlapped with the encoder backward.
-# OFF by default: it cannot be validated on RCCL from a one-GPU box, and under gloo (two ranks on one GPU) the
-# collective after the first asynchronous one never completes at the bench sizes (tools/rehearse_dp.sh).
-DP_OVERLAP = os.environ.get("SERL_AMD_DP_OVERLAP", "0") != "0"   # all-reduce of the head gradients overlapped with the encoder backward
-
 from ..train_state import ADAM_B1, ADAM_B2, ADAM_EPS, TempState, TrainState, bias_corrections
 
 
@@ -218,9 +205,8 @@ class SACLearner(Agent):
             ops.copy2d(z, ldz, src.data_ptr() + 4 * lo * cfg.obs_dim, cfg.obs_dim, B, cfg.obs_dim, st_)
 
     def _features_bwd(self, tag, store, grads, feats, lo, B, ws, st, dz_ptr, lddz, need_encoder, gside=None,
-                      on_head_grads=None, dz_slabs=(1, 0)):
-        if on_head_grads is not None:      # no trainable feature stage for state inputs: all gradients are enqueued
-            on_head_grads()
+                      dz_slabs=(1, 0)):
+        pass                               # no trainable feature stage for state inputs
 
     # ------------------------------------------------------------------ update
     def update(self, batch, utd_ratio: int):
@@ -271,14 +257,12 @@ class SACLearner(Agent):
         main = torch.cuda.current_stream()
         s0, s1 = ss["s"]
         zT_all = nlogp_all = None
-        zP = ws.ptr("zC_pi", (B, ldz)) if ACTOR_RUNAHEAD else zC     # critic input of the actor step
-        # pixel learners: fused gather + crop of the minibatch rows (feats["crop"]).  With the run-ahead stream only the
-        # first minibatch is augmented up front; minibatch j+1 is augmented on that stream during critic step j.
+        zP = ws.ptr("zC_pi", (B, ldz))                               # critic input of the actor step
+        # pixel learners: fused gather + crop of all B*U rows up front (feats["crop"])
         crop = feats.get("crop")
-        chunked_crop = crop is not None and ACTOR_RUNAHEAD and CHUNKED_CROP and utd_ratio > 1
         if crop is not None:
-            crop(0, B if chunked_crop else n, st)
-        if ACTOR_RUNAHEAD:
+            crop(0, n, st)
+        if True:
             # The actor's parameters do not change inside the UTD loop (its step comes after it, :235), so its
             # pass over next_obs -- encoder, trunk, policy sample: a third of the forward conv work -- does not
             # depend on the critic steps.  It runs for all U minibatches on its own stream, ahead of the loop, and
@@ -296,9 +280,6 @@ class SACLearner(Agent):
             sta = astream.cuda_stream
 
             def enqueue_actor(j):
-                if chunked_crop and j > 0:
-                    crop(j * B, B, sta)
-                    cdone[j].record(astream)
                 # the actor's parameters are constant during the loop: its S-format weight copies are made once
                 self._features([("A", actor.store, "next")], feats, j * B, B, ws, sta, prep=(j == 0))
                 nn.policy_fwd(cfg, "A", actor.store, zA, ldz, B, ws, sta, step_keys[j][0], rank * B, Bg,
@@ -324,34 +305,22 @@ class SACLearner(Agent):
             tstore = target.store
             if m0 is None:
                 tstore, m0, mstride = self._gathered_target(idx, target.store), 0, 1
-            if ACTOR_RUNAHEAD:
+            if True:
                 # target chain on the main stream, critic chain on a side stream, next action from the actor stream
-                if chunked_crop and i > 0:
-                    main.wait_event(ss["cdone"][i])
                 zT = zT_all + 4 * i * B * ldz
                 self._features([("T", target.store, "next"), ("C", critic.store, "obs")],
                                feats, lo, B, ws, st, save_tag="C", trunk_streams={"C": s1}, fork=ss["fork"],
                                z_ptrs={"T": zT})
                 ops.phase("features_fwd")
-                if ACTOR_GATE:           # start pass i+1 when the main stream leaves its (HBM-bound) encoder forward
-                    ss["agate"].record(main)
-                    astream.wait_event(ss["agate"])
+                # start pass i+1 when the main stream leaves its (HBM-bound) encoder forward
+                ss["agate"].record(main)
+                astream.wait_event(ss["agate"])
                 if i + 1 < utd_ratio:
                     enqueue_actor(i + 1)
                 else:                    # behind the last pass: the actor's pass over obs for the actor step
                     enqueue_actor_obs()
                 main.wait_event(ss["adone"][i])
                 nlogp = nlogp_all + 4 * i * B if self.backup_entropy else None
-            else:
-                # encoders of the three passes in grouped launches on the main stream, then three concurrent chains:
-                #   main: actor trunk + policy (next action -> zT)      side 0: target trunk      side 1: critic trunk + Q
-                self._features([("A", actor.store, "next"), ("T", target.store, "next"), ("C", critic.store, "obs")],
-                               feats, lo, B, ws, st, save_tag="C", trunk_streams={"T": s0, "C": s1}, fork=ss["fork"])
-                ops.phase("features_fwd")
-                nlogp = nn.policy_fwd(cfg, "A", actor.store, zA, ldz, B, ws, st, key_act, rank * B, Bg,
-                                      zT + 4 * cfg.latent, ldz, want_logp=self.backup_entropy)
-                ss["join"][0].record(s0)
-                main.wait_event(ss["join"][0])
             next_q = nn.ensemble_fwd(cfg, "T", tstore, m0, mstride, emin, zT, ldz, B, ws, st, save=False)
             st1 = s1.cuda_stream
             ops.copy2d(zC + 4 * cfg.latent, ldz, actions.data_ptr() + 4 * lo * A, A, B, A, st1)
@@ -373,28 +342,12 @@ class SACLearner(Agent):
                                     dinp="slabs" if cfg.pixel else None)
             dinp, dz_slabs = (dslab[0], dslab[1:]) if dslab is not None else (None, (1, 0))
             ops.phase("ensemble_bwd")
-            # data parallel: the head / trunk gradient leaves (everything behind the image_encoder/* prefix of the flat
-            # buffer) are complete before the conv backward starts; their all-reduce runs behind the side stream's
-            # kernels while the encoder backward proceeds, only the encoder prefix is reduced on the critical path
-            head_work = []
-            enc_n = critic.store.layout.prefix_size("image_encoder") if DP_OVERLAP else 0
-
-            def reduce_heads():
-                if dist is not None and DP_OVERLAP:
-                    head_work.append(dist.all_reduce_sum_async(cgr.flat[enc_n:], gside.side))
             self._features_bwd("C", critic.store, cgr, feats, lo, B, ws, st, dinp, ldz, need_encoder=True, gside=gside,
-                               on_head_grads=reduce_heads, dz_slabs=dz_slabs)
+                               dz_slabs=dz_slabs)
             gside.join()
             ops.phase("features_bwd")
-            if dist is not None:
-                if not DP_OVERLAP:
-                    dist.all_reduce_sum(cgr.flat)
-                else:
-                    if enc_n:
-                        dist.all_reduce_sum(cgr.flat[:enc_n])
-                    for w in head_work:
-                        if w is not None:
-                            w.wait()
+            if dist is not None:      # data parallel: one blocking all-reduce(sum) of the flat gradient per critic step
+                dist.all_reduce_sum(cgr.flat)
             critic.step += 1
             bc1, bc2 = bias_corrections(critic.step)
             ops.adam_polyak(critic.store.base, critic.mu.data_ptr(), critic.nu.data_ptr(), cgr.base,
@@ -404,16 +357,11 @@ class SACLearner(Agent):
         # ---- actor step on the last minibatch (sac_learner.py:120-144, 235)
         ops.phase("actor")
         lo = (utd_ratio - 1) * B
-        if ACTOR_RUNAHEAD:
-            # the actor's own pass over obs (encoder, trunk, policy sample) ran ahead behind the last next_obs pass;
-            # only the critic pass with the post-UTD critic parameters is left on the main stream
-            main.wait_event(ss["aobs"])
-            self._features([("C", critic.store, "obs")], feats, lo, B, ws, st, z_ptrs={"C": zP})
-            logp = ws.ptr("logp_A", (B,))
-        else:
-            self._features([("A", actor.store, "obs"), ("C", critic.store, "obs")], feats, lo, B, ws, st, save_tag="A")
-            logp = nn.policy_fwd(cfg, "A", actor.store, zA, ldz, B, ws, st, key_pi, rank * B, Bg, zP + 4 * cfg.latent,
-                                 ldz, save=True)
+        # the actor's own pass over obs (encoder, trunk, policy sample) ran ahead behind the last next_obs pass;
+        # only the critic pass with the post-UTD critic parameters is left on the main stream
+        main.wait_event(ss["aobs"])
+        self._features([("C", critic.store, "obs")], feats, lo, B, ws, st, z_ptrs={"C": zP})
+        logp = ws.ptr("logp_A", (B,))
         zC = zP                                            # critic input of the actor step
         q = nn.ensemble_fwd(cfg, "C", critic.store, 0, 1, E, zC, ldz, B, ws, st, save=True)
         ops.actor_loss(q, E, B, logp, log_temp, info.data_ptr() + 8, st)

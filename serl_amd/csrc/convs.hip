@@ -4,6 +4,8 @@
 // ReLU, serl/networks/encoders/two_d4pg_encoder.py:30-38) and the same split-K / fixed-order reduction for
 // the weight gradient.  The first layer reads the uint8 pixels directly: integers 0..255 are exact in
 // bf16, so its A operand has no lo plane and 1/255 (pixel_multiplexer.py:27) is applied to the accumulator.
+#include <mutex>
+
 #include "conv_geom.h"
 #include "sgemm.h"
 
@@ -627,20 +629,20 @@ extern "C" int serl_convs_dgrad(int ngroups, const void* const* dz, const void* 
   return s_launch_by_n(S_DGRAD, p, max_m, g.C, 1, ngroups * stride * stride, (hipStream_t)stream, "convs_dgrad");
 }
 
-extern "C" int serl_convs_wgrad(int ngroups, const void* const* x, const void* const* dz, float* const* dw,
-                                float* const* dbias, float* workspace, long long workspace_bytes, int in_u8, int B,
-                                int IH, int IW, int C, int KH, int KW, int stride, int F, void* stream) {
-  SERL_CHECK_ARG(ngroups >= 1 && ngroups <= MAXG, "convs_wgrad: ngroups must be in [1,%d]", MAXG);
+static int convs_wgrad_impl(const char* name, int ngroups, const void* const* x, const void* const* dz,
+                            float* const* dw, float* const* dbias, float* workspace, long long workspace_bytes,
+                            int in_u8, int B, int IH, int IW, int C, int KH, int KW, int stride, int F, void* stream) {
+  SERL_CHECK_ARG(ngroups >= 1 && ngroups <= MAXG, "%s: ngroups must be in [1,%d]", name, MAXG);
   ConvGeom g;
   if (int e = make_geom(g, B, IH, IW, C, KH, KW, stride, F)) return e;
-  SERL_CHECK_ARG(F % 8 == 0 && (in_u8 ? KW * C <= 32 : C % 8 == 0), "convs_wgrad: need F %% 8 == 0 and C %% 8 == 0 (uint8 input: KW*C <= 32)");
-  SERL_CHECK_ARG(all_aligned16(dz, ngroups) && (in_u8 || all_aligned16(x, ngroups)), "convs_wgrad: S-format tensors must be 16-byte aligned");
+  SERL_CHECK_ARG(F % 8 == 0 && (in_u8 ? KW * C <= 32 : C % 8 == 0), "%s: need F %% 8 == 0 and C %% 8 == 0 (uint8 input: KW*C <= 32)", name);
+  SERL_CHECK_ARG(all_aligned16(dz, ngroups) && (in_u8 || all_aligned16(x, ngroups)), "%s: S-format tensors must be 16-byte aligned", name);
   int nsplit, klen;
   wgrad_plan(g, ngroups, nsplit, klen);
   const int kkc = KH * KW * C;
   const long long need = (long long)ngroups * nsplit * (kkc + 1) * F * 4ll;
-  SERL_CHECK_ARG(workspace != nullptr && workspace_bytes >= need, "convs_wgrad: workspace too small (%lld < %lld)",
-                 workspace_bytes, need);
+  SERL_CHECK_ARG(workspace != nullptr && workspace_bytes >= need, "%s: split-K slabs need %lld bytes, %lld available",
+                 name, need, workspace_bytes);
   hipStream_t st = (hipStream_t)stream;
   int e;
 #define FILLW(p)                                                                                      \
@@ -657,4 +659,50 @@ extern "C" int serl_convs_wgrad(int ngroups, const void* const* x, const void* c
   launch_wgrad_reduce(ra, ngroups, st);
   SERL_CHECK_LAUNCH("wgrad_reduce");
   return SERL_OK;
+}
+
+extern "C" int serl_convs_wgrad(int ngroups, const void* const* x, const void* const* dz, float* const* dw,
+                                float* const* dbias, float* workspace, long long workspace_bytes, int in_u8, int B,
+                                int IH, int IW, int C, int KH, int KW, int stride, int F, void* stream) {
+  return convs_wgrad_impl("convs_wgrad", ngroups, x, dz, dw, dbias, workspace, workspace_bytes, in_u8, B, IH, IW, C, KH,
+                          KW, stride, F, stream);
+}
+
+// ---- the same weight gradient for callers that cannot allocate (HIP graph capture, serving loops, harnesses that
+// forbid hipMalloc): the split-K slabs live in a file-scope device array instead of a caller-provided workspace.
+// Every GPU the library runs on holds its own 64 MiB copy of the array until the process ends.  In host code the
+// array's name is only a stand-in: the device address is looked up once per device with hipGetSymbolAddress and
+// that pointer is what the kernels get.  The slabs are written completely by the first kernel before the reduction
+// reads them, so nothing has to be cleared between calls; calls that overlap on one GPU (two streams) race on it.
+#define SERL_WGRAD_SCRATCH_BYTES (64ll << 20)
+#define SERL_MAX_DEVICES 64
+static __device__ __align__(256) float scratch[SERL_WGRAD_SCRATCH_BYTES / 4];
+static float* g_scratch_ptr[SERL_MAX_DEVICES] = {};
+static std::mutex g_scratch_mu;
+
+static int wgrad_scratch_ptr(float** out) {
+  int dev = -1;
+  SERL_CHECK_HIP(hipGetDevice(&dev), "convs_wgrad_noalloc");
+  SERL_CHECK_ARG(dev >= 0 && dev < SERL_MAX_DEVICES, "convs_wgrad_noalloc: device ordinal %d out of range", dev);
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  if (g_scratch_ptr[dev] == nullptr) {         // set-up, once per device, with that device current
+    void* ptr = nullptr;
+    SERL_CHECK_HIP(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)), "convs_wgrad_noalloc");
+    SERL_CHECK_ARG(ptr != nullptr, "convs_wgrad_noalloc: hipGetSymbolAddress returned NULL");
+    g_scratch_ptr[dev] = (float*)ptr;
+  }
+  *out = g_scratch_ptr[dev];
+  return SERL_OK;
+}
+
+extern "C" long long serl_convs_wgrad_noalloc_max_bytes(void) { return SERL_WGRAD_SCRATCH_BYTES; }
+
+extern "C" int serl_convs_wgrad_noalloc(int ngroups, const void* const* x, const void* const* dz, float* const* dw,
+                                        float* const* dbias, int in_u8, int B, int IH, int IW, int C, int KH, int KW,
+                                        int stride, int F, void* stream) {
+  float* ptr = nullptr;
+  if (int e = wgrad_scratch_ptr(&ptr)) return e;
+  // rejects shapes whose slabs exceed the array ("... need N bytes, 67108864 available")
+  return convs_wgrad_impl("convs_wgrad_noalloc", ngroups, x, dz, dw, dbias, ptr, SERL_WGRAD_SCRATCH_BYTES, in_u8, B, IH,
+                          IW, C, KH, KW, stride, F, stream);
 }

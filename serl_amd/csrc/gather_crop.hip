@@ -9,7 +9,8 @@
 //
 // One block = one sample x {obs,next} x TH output rows.  Phase 1 stages the source rows in LDS with
 // 16-byte coalesced loads, phase 2 de-interleaves/shifts pixel by pixel inside LDS, phase 3 streams
-// the finished rows out with 16-byte coalesced stores.
+// the finished rows out with 16-byte coalesced stores.  Frame rows whose byte length W*3 is not a multiple of 16
+// (84x84, 100x100: the usual DrQ sizes) take the same kernel with 4-byte or 1-byte lanes (template VecT).
 #include "common.h"
 
 #define GC_TH 8
@@ -22,8 +23,9 @@ struct GcArgs {
   int n, H, W, S, T, t0, pad, cap;
 };
 
-template <bool PACKED>
+template <bool PACKED, typename VecT>
 __global__ __launch_bounds__(256) void gather_crop_kernel(const GcArgs a) {
+  constexpr int VB = (int)sizeof(VecT);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int j = blockIdx.x, y0 = blockIdx.y * GC_TH;
   const int S = a.S, W = a.W, H = a.H, T = a.T;
@@ -41,7 +43,7 @@ __global__ __launch_bounds__(256) void gather_crop_kernel(const GcArgs a) {
     w0 = a.indx[j] - (T - 1);
     if (w0 < 0) w0 += a.cap - (T - 1);  // python negative index into the (cap - S)-long window view
   }
-  const int vec_per_row = srow / 16;
+  const int vec_per_row = srow / VB;
   const int nvec = nsrc * rows * vec_per_row;
   for (int v = threadIdx.x; v < nvec; v += 256) {
     const int p = v / (rows * vec_per_row);
@@ -50,9 +52,9 @@ __global__ __launch_bounds__(256) void gather_crop_kernel(const GcArgs a) {
     int sy = y0 + r + dy;
     sy = sy < 0 ? 0 : (sy >= H ? H - 1 : sy);
     const unsigned char* g;
-    if (PACKED) g = a.src + ((long long)j * H + sy) * srow + q * 16;
-    else g = a.src + ((w0 + p + a.t0) * H + sy) * (long long)rowb + q * 16;
-    *(uint4*)(s_src + (p * GC_TH + r) * srow + q * 16) = *(const uint4*)g;
+    if (PACKED) g = a.src + ((long long)j * H + sy) * srow + q * VB;
+    else g = a.src + ((w0 + p + a.t0) * H + sy) * (long long)rowb + q * VB;
+    *(VecT*)(s_src + (p * GC_TH + r) * srow + q * VB) = *(const VecT*)g;
   }
   __syncthreads();
 
@@ -77,23 +79,29 @@ __global__ __launch_bounds__(256) void gather_crop_kernel(const GcArgs a) {
 
   // ---- phase 3: LDS -> global, 16 B per lane
   unsigned char* out = a.out + ((long long)j * H + y0) * orow;
-  const int ovec = rows * orow / 16;
-  for (int v = threadIdx.x; v < ovec; v += 256) *(uint4*)(out + v * 16) = *(const uint4*)(s_out + v * 16);
+  const int ovec = rows * orow / VB;
+  for (int v = threadIdx.x; v < ovec; v += 256) *(VecT*)(out + v * VB) = *(const VecT*)(s_out + v * VB);
 }
 
 static int gc_launch(const GcArgs& a, bool packed, hipStream_t st) {
   const int rowb = a.W * 3;
   SERL_CHECK_ARG(a.n >= 1 && a.S >= 1 && a.t0 >= 0 && a.t0 + a.S <= a.T, "gather_crop: frames t0..t0+S-1 outside the window");
-  SERL_CHECK_ARG(rowb % 16 == 0, "gather_crop: W*3 must be a multiple of 16 bytes");
-  SERL_CHECK_ARG(((uintptr_t)a.src & 15) == 0 && ((uintptr_t)a.out & 15) == 0, "gather_crop: buffers must be 16-byte aligned");
-  SERL_CHECK_ARG(a.H % GC_TH == 0, "gather_crop: H must be a multiple of %d", GC_TH);
+  SERL_CHECK_ARG(a.H >= 1 && a.W >= 1, "gather_crop: bad image size");
+  // lane width: every staged row, output row and tile start is a multiple of W*3 bytes from the buffer start
+  const uintptr_t al = (uintptr_t)a.src | (uintptr_t)a.out | (uintptr_t)rowb;
+  const int vb = (al & 15) == 0 ? 16 : (al & 3) == 0 ? 4 : 1;
   const int srow = packed ? rowb * a.T : rowb;
   const int nsrc = packed ? 1 : a.S;
   const size_t lds = (size_t)nsrc * GC_TH * srow + (size_t)GC_TH * rowb * a.S;
   SERL_CHECK_ARG(lds <= 64 * 1024, "gather_crop: tile needs %zu B of LDS", lds);
-  dim3 grid(a.n, a.H / GC_TH);
-  if (packed) hipLaunchKernelGGL(gather_crop_kernel<true>, grid, dim3(256), lds, st, a);
-  else hipLaunchKernelGGL(gather_crop_kernel<false>, grid, dim3(256), lds, st, a);
+  dim3 grid(a.n, cdiv(a.H, GC_TH));
+#define GC_LAUNCH(P, V) hipLaunchKernelGGL((gather_crop_kernel<P, V>), grid, dim3(256), lds, st, a)
+  if (packed) {
+    if (vb == 16) GC_LAUNCH(true, uint4); else if (vb == 4) GC_LAUNCH(true, uint32_t); else GC_LAUNCH(true, unsigned char);
+  } else {
+    if (vb == 16) GC_LAUNCH(false, uint4); else if (vb == 4) GC_LAUNCH(false, uint32_t); else GC_LAUNCH(false, unsigned char);
+  }
+#undef GC_LAUNCH
   SERL_CHECK_LAUNCH("gather_crop");
   return SERL_OK;
 }

@@ -8,8 +8,27 @@ class FrameWindows:
     fuses the gather with `_unpack` and the random-shift crop in one kernel; `materialize()` returns
     the packed (n,H,W,3,S+1) uint8 tensor the reference would have produced."""
 
-    def __init__(self, frames, capacity, indx, num_stack):
+    def __init__(self, frames, capacity, indx, num_stack, first_rows=None):
         self.frames, self.capacity, self.indx, self.num_stack = frames, int(capacity), indx, int(num_stack)
+        # The reference gathers pixels at sample time, so its batches cannot change afterwards.  A lazy window batch
+        # can: an insert() that lands on one of its rows before the learner has enqueued the gather would change it.
+        # The owning buffer therefore keeps un-consumed batches registered and, before overwriting a row that one of
+        # them references (`first_rows`: host int64, first store row of every window), calls pin(): the packed
+        # tensor is gathered then, and DrQLearner.update reads that instead of the store.
+        self.first_rows = first_rows
+        self.packed = None
+        self.consumed = False
+
+    def touches(self, row) -> bool:
+        if self.first_rows is None:
+            return False
+        d = int(row) - self.first_rows
+        return bool(((d >= 0) & (d <= self.num_stack)).any())
+
+    def pin(self):
+        if self.packed is None and not self.consumed:
+            self.packed = self.materialize()
+        return self.packed
 
     @property
     def shape(self):

@@ -47,6 +47,7 @@ class MemoryEfficientReplayBuffer(ReplayBuffer):
         self._is_correct_index = np.full(capacity, False, dtype=bool)
         super().__init__(Dict(host_spaces), action_space, capacity, next_observation_space=next_space)
         self._frames = None
+        self._pending = []          # weak references to lazy window batches the learner has not gathered yet
         if self._device is not None:
             import torch
             self._frames = {k: torch.zeros((capacity, *self._frame_shape[k]), dtype=torch.uint8, device=self._device)
@@ -58,12 +59,28 @@ class MemoryEfficientReplayBuffer(ReplayBuffer):
         self._is_correct_index[at] = valid
         if self._frames is not None:
             import torch
+            self._protect_pending(at)
             for k, f in frames.items():
                 self._frames[k][at].copy_(torch.from_numpy(np.ascontiguousarray(f)))
         else:
             row = dict(row)
             row["observations"] = dict(row["observations"], **frames)
         ReplayBuffer.insert(self, row)
+
+    def _protect_pending(self, at):
+        """Row `at` of the device frame store is about to be overwritten: batches sampled earlier whose windows hold
+        it, and which the learner has not gathered yet, are gathered now (the reference's batches are snapshots:
+        memory_efficient_replay_buffer.py:155-160 copies at sample time)."""
+        live = []
+        for ref in self._pending:
+            fw = ref()
+            if fw is None or fw.consumed or fw.packed is not None:
+                continue
+            if fw.touches(at):
+                fw.pin()
+            else:
+                live.append(ref)
+        self._pending = live
 
     def _row_at(self, idx):
         row = take(self.dataset_dict, idx)
@@ -155,6 +172,12 @@ class MemoryEfficientReplayBuffer(ReplayBuffer):
         assert not args, f"unknown sample args {sorted(args)}"
         out = to_device(batch, dev).unfreeze()
         ix = torch.from_numpy(indx.astype(np.int64)).pin_memory().to(self._device, non_blocking=True)
+        import weakref
+        S = self._num_stack
+        first = indx.astype(np.int64) - S
+        first[first < 0] += self._capacity - S                  # the negative-index wrap of the window view (C.7)
         for k in self.pixel_keys:
-            out["observations"][k] = FrameWindows(self._frames[k], self._capacity, ix, self._num_stack)
+            fw = FrameWindows(self._frames[k], self._capacity, ix, S, first_rows=first)
+            self._pending.append(weakref.ref(fw))
+            out["observations"][k] = fw
         return freeze(out)

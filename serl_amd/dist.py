@@ -23,19 +23,6 @@ class DataParallel:
             self._td.all_reduce(tensor, op=self._td.ReduceOp.SUM, group=self.group)
         return tensor
 
-    def all_reduce_sum_async(self, tensor, stream=None):
-        """Start the all-reduce behind the work enqueued so far on `stream` (a torch stream; default: the current
-        one) and return the work handle (None on one rank): `handle.wait()` makes the then-current stream wait for
-        the result.  Used to overlap the reduction of the gradient leaves that are complete early in the backward
-        pass (heads, trunk: 81 % of the bytes) with the rest of it (the conv encoder's backward)."""
-        if self.world_size == 1:
-            return None
-        import torch
-        if stream is None:
-            return self._td.all_reduce(tensor, op=self._td.ReduceOp.SUM, group=self.group, async_op=True)
-        with torch.cuda.stream(stream):
-            return self._td.all_reduce(tensor, op=self._td.ReduceOp.SUM, group=self.group, async_op=True)
-
 
 def shard_rows(n_global_rows: int, utd_ratio: int, rank: int, world_size: int):
     """Row indices (into the global B_g*U batch) that `rank` owns: inside every contiguous UTD slice of

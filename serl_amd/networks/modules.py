@@ -32,8 +32,8 @@ class Workspace:
         if t is None or tuple(t.shape) != shape or t.dtype != dtype:
             t = torch.zeros(shape, dtype=dtype, device=self.device)
             # the zero fill runs on torch's current stream; kernels that use the buffer may run on a side stream
-            # (sac_learner._side_streams): make the fill visible everywhere. Only on first use of a name/shape.
-            torch.cuda.synchronize(self.device)
+            # (sac_learner._side_streams): wait for that one stream (not the device). Only on first use of a name/shape.
+            torch.cuda.current_stream(self.device).synchronize()
             self._t[name] = t
         return t
 

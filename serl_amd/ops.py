@@ -187,6 +187,13 @@ def convs_wgrad(xs, dzs, dws, dbs, workspace, workspace_bytes, in_u8, B, IH, IW,
         TIMER.rec(ev[1], stream)
 
 
+def convs_wgrad_noalloc(xs, dzs, dws, dbs, in_u8, B, IH, IW, C, KH, KW, stride, F, stream):
+    """serl_convs_wgrad with the split-K slabs in the library's static device array: no workspace, no allocation."""
+    n = len(xs)
+    px, kx = ptr_table(xs); pz, kz = ptr_table(dzs); pw, kw = ptr_table(dws); pb, kb = ptr_table(dbs)
+    call("serl_convs_wgrad_noalloc", n, px, pz, pw, pb, int(in_u8), B, IH, IW, C, KH, KW, stride, F, stream)
+
+
 def gemm(a, b, c, bias, nbatch, M, N, K, *, a_zs=0, a_ms, a_ks, b_zs=0, b_ks, b_ns, c_zs=0, c_ms,
          bias_zs=0, seglen=None, a_ss=0, b_ss=0, nsplit=1, c_split_stride=0, relu=False, accumulate=False,
          a_kcontig=True, b_ncontig=True, stream=0):

@@ -11,8 +11,9 @@ from . import _lib
 
 
 def PRNGKey(seed: int) -> np.ndarray:
-    seed = int(seed) & 0xFFFFFFFFFFFFFFFF
-    return np.array([seed >> 32, seed & 0xFFFFFFFF], dtype=np.uint32)
+    seed = int(seed)                     # x64 off: a negative int32 seed has high word 0 (oracle/prng.py prng_key)
+    hi = (seed >> 32) & 0xFFFFFFFF if seed >= 0 else 0
+    return np.array([hi, seed & 0xFFFFFFFF], dtype=np.uint32)
 
 
 def split(key, num: int = 2) -> np.ndarray:

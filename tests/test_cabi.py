@@ -72,7 +72,7 @@ def test_s_format_entry_points_validate_before_touching_the_device():
         ops.convs_fwd([16], [8], [16], [16], False, 1, 8, 8, 8, 3, 3, 2, 8, True, 0)
     with pytest.raises(ValueError, match="stride"):
         ops.convs_dgrad([16], [16], [16], [16], 1, 9, 9, 8, 3, 3, 3, 8, 0)
-    with pytest.raises(ValueError, match="workspace too small"):
+    with pytest.raises(ValueError, match="slabs need 2336 bytes, 4 available"):
         ops.convs_wgrad([16], [16], [16], [16], 16, 4, False, 1, 8, 8, 8, 3, 3, 2, 8, 0)
     with pytest.raises(ValueError, match="ngroups"):
         ops.sle_fwd([16] * 9, [16] * 9, [16] * 9, 8, 1, 4, 8, 8, 0)

@@ -84,7 +84,18 @@ def test_dp_gradient_equals_global_gloo():
     assert r0.tolist() == [0, 1, 2, 3, 8, 9, 10, 11] and sorted(np.concatenate([r0, r1]).tolist()) == list(range(16))
 
 
-def _gpu_worker(rank, world, port, out):
+def _gpu_case(large):
+    """small: the round-1 case; large: a global batch of 512 rows (2 x 256 per rank) through the E1 conv stack."""
+    keys = ("wrist_1", "wrist_2")
+    if large:
+        return dict(keys=keys, H=64, W=64, S=3, bg=512, utd=2, kw=dict(
+            cnn_features=(32, 64, 128, 256), cnn_filters=(3, 3, 3, 3), cnn_strides=(2, 2, 2, 2), latent_dim=64,
+            num_qs=10, num_min_qs=2, critic_layer_norm=True, backup_entropy=False, init_temperature=0.1))
+    return dict(keys=keys, H=32, W=32, S=2, bg=8, utd=2,
+                kw=dict(num_qs=4, num_min_qs=2, critic_layer_norm=True, backup_entropy=True))
+
+
+def _gpu_worker(rank, world, port, out, large=False):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helpers import make_pixel_batch, pixel_spaces
     from oracle import learner as ol
@@ -93,17 +104,16 @@ def _gpu_worker(rank, world, port, out):
     _init(rank, world, port)
     torch.cuda.set_device(0)
     dp = DataParallel()
-    keys = ("wrist_1", "wrist_2")
-    H = W = 32; S = 2; bg, utd = 8, 2
+    c = _gpu_case(large)
+    keys, H, W, S, bg, utd = c["keys"], c["H"], c["W"], c["S"], c["bg"], c["utd"]
     obs_space, act_space = pixel_spaces(keys, H, W, S, 19, 7)
-    agent = DrQLearner.create(5, obs_space, act_space, pixel_keys=keys, num_qs=4, num_min_qs=2, critic_layer_norm=True,
-                              backup_entropy=True, dist=dp)
+    agent = DrQLearner.create(5, obs_space, act_space, pixel_keys=keys, dist=dp, **c["kw"])
     batch = make_pixel_batch(np.random.default_rng(2), bg * utd, keys, H, W, S, 19, 7, packed=True)
     rows = shard_rows(bg * utd, utd, rank, world)
     local = ol.tree_map(lambda a: a[rows], batch)
     new, info = agent.update(local, utd, pixel_keys=keys)
-    if rank == 0:
-        out.put((info, new.critic.store.flat.cpu().numpy(), new.actor.store.flat.cpu().numpy(),
+    if rank == 0:       # host copies only: a CUDA tensor on the queue would need the producer alive at get() time (IPC)
+        out.put((dict(info), new.critic.store.flat.cpu().numpy(), new.actor.store.flat.cpu().numpy(),
                  agent._shared["critic_grads"].flat.cpu().numpy()))
     import torch.distributed as td
     td.barrier()
@@ -111,26 +121,26 @@ def _gpu_worker(rank, world, port, out):
 
 
 @pytest.mark.gpu
-def test_dp_learner_two_ranks_equals_one(dev):
+@pytest.mark.parametrize("large", [False, True])
+def test_dp_learner_two_ranks_equals_one(dev, large):
     from helpers import make_pixel_batch, pixel_spaces
     from serl_amd.agents import DrQLearner
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = 31500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_gpu_worker, args=(r, 2, port, out)) for r in range(2)]
+    procs = [ctx.Process(target=_gpu_worker, args=(r, 2, port, out, large)) for r in range(2)]
     for p in procs:
         p.start()
     info2, critic2, actor2, grads2 = out.get(timeout=240)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    keys = ("wrist_1", "wrist_2")
-    H = W = 32; S = 2
+    c = _gpu_case(large)
+    keys, H, W, S, bg, utd = c["keys"], c["H"], c["W"], c["S"], c["bg"], c["utd"]
     obs_space, act_space = pixel_spaces(keys, H, W, S, 19, 7)
-    agent = DrQLearner.create(5, obs_space, act_space, pixel_keys=keys, num_qs=4, num_min_qs=2, critic_layer_norm=True,
-                              backup_entropy=True)
-    batch = make_pixel_batch(np.random.default_rng(2), 16, keys, H, W, S, 19, 7, packed=True)
-    new, info1 = agent.update(batch, 2, pixel_keys=keys)
+    agent = DrQLearner.create(5, obs_space, act_space, pixel_keys=keys, **c["kw"])
+    batch = make_pixel_batch(np.random.default_rng(2), bg * utd, keys, H, W, S, 19, 7, packed=True)
+    new, info1 = agent.update(batch, utd, pixel_keys=keys)
     for k in info1:
         assert abs(info1[k] - info2[k]) <= 1e-3 * max(abs(info1[k]), 1e-2), (k, info1[k], info2[k])
     g1 = agent._shared["critic_grads"].flat.cpu().numpy()

@@ -399,3 +399,209 @@ def test_learner_thread_and_acting_thread(dev, repeat):
     assert res["learn"][1] == solo_info
     assert torch.equal(res["learn"][0].critic.store.flat, solo_agent.critic.store.flat)
     assert torch.equal(res["learn"][0].actor.store.flat, solo_agent.actor.store.flat)
+
+
+def test_drq_pixel_keys_in_caller_order(dev):
+    """pixel_keys=("wrist_2", "wrist_1"): the augmentation keys are split in the caller's order
+    (drq_learner.py:131-137) while the encoder visits the cameras in sorted order with per-camera weights
+    (two_d4pg_encoder.py:23-29).  One update vs the oracle, augmented images bit-exact."""
+    from oracle import learner as ol
+    from serl_amd.agents import DrQLearner
+    keys = ("wrist_2", "wrist_1")
+    H = W = 32; S = 2; B, U = 6, 1
+    obs_space, act_space = pixel_spaces(keys, H, W, S, 19, 7)
+    agent = DrQLearner.create(3, obs_space, act_space, pixel_keys=keys, num_qs=4, num_min_qs=2, critic_layer_norm=True)
+    ostate, ocfg = agent_to_oracle(agent)
+    assert tuple(ocfg["pixel_keys"]) == keys
+    batch = make_pixel_batch(np.random.default_rng(4), B * U, keys, H, W, S, 19, 7, packed=True)
+    collect = []
+    ostate, oinfo = ol.drq_update(ostate, ocfg, batch, U, collect=collect)
+    agent, info = agent.update(batch, U, pixel_keys=keys)
+    ws = agent._ws(B)
+    for side, okey in (("obs", "observations"), ("next", "next_observations")):
+        for cam in keys:
+            got = ws.tensor(f"aug_{side}_{cam}", (B * U, H, W, 3 * S), torch.uint8).cpu().numpy()
+            assert np.array_equal(got.reshape(B * U, H, W, 3, S), collect[0][okey][cam]), f"aug {side} {cam}"
+    assert_info_close(info, oinfo, rtol=1e-3)
+    assert np.array_equal(agent.rng, ostate["rng"])
+    # swapping the two cameras' images must change the result (per-camera weights): guards against a silent re-sort
+    swapped = dict(batch, observations={"wrist_1": batch["observations"]["wrist_2"],
+                                        "wrist_2": batch["observations"]["wrist_1"],
+                                        "state": batch["observations"]["state"]})
+    agent0 = DrQLearner.create(3, obs_space, act_space, pixel_keys=keys, num_qs=4, num_min_qs=2, critic_layer_norm=True)
+    _, info_sw = agent0.update(swapped, U, pixel_keys=keys)
+    assert abs(info_sw["critic_loss"] - info["critic_loss"]) > 1e-6
+
+
+def test_update_does_not_touch_the_input_agent(dev):
+    """Functional semantics (sac_learner.py:221-238 returns a new agent): update() leaves no attribute on `self`."""
+    from serl_amd.agents import DrQLearner
+    keys = ("pixels",)
+    obs_space, act_space = pixel_spaces(keys, 32, 32, 1, 5, 3)
+    agent = DrQLearner.create(0, obs_space, act_space, pixel_keys=keys)
+    before = dict(vars(agent))
+    snap = {n: getattr(agent, n).store.flat.clone() for n in ("actor", "critic", "target_critic")}
+    agent.update(make_pixel_batch(np.random.default_rng(0), 8, keys, 32, 32, 1, 5, 3), 2, pixel_keys=keys)
+    assert vars(agent).keys() == before.keys() and all(vars(agent)[k] is before[k] for k in before)
+    for n, t in snap.items():
+        assert torch.equal(getattr(agent, n).store.flat, t)
+
+
+def test_insert_between_sample_and_update(dev):
+    """The reference gathers pixels at sample time (memory_efficient_replay_buffer.py:155-160): inserts that land
+    between `next(iterator)` and `update()` must not change the batch.  The device buffer's lazy windows are pinned
+    when an insert is about to overwrite one of their rows."""
+    from serl_amd.agents import DrQLearner
+    from serl_amd.data import MemoryEfficientReplayBuffer
+    from helpers import rollout_transitions
+    keys = ("wrist_1", "wrist_2")
+    H = W = 32; S = 3
+    cap = 120
+    obs_space, act_space = pixel_spaces(keys, H, W, S, 19, 7)
+    bufs = [MemoryEfficientReplayBuffer(obs_space, act_space, cap, pixel_keys=keys, device=d) for d in (None, "cuda")]
+    trs = list(rollout_transitions(np.random.default_rng(8), 400, keys, H, W, S, 19, 7, episode_len=17))
+    for tr in trs[:300]:                                   # ring is full and has wrapped: every insert overwrites rows
+        for b in bufs:
+            b.insert(tr)
+    for b in bufs:
+        b.seed(5)
+    args = dict(batch_size=64, pack_obs_and_next_obs=True)
+    lazy = next(bufs[1].get_iterator(queue_size=1, sample_args=args))
+    hostb = bufs[0].sample(**args)                         # snapshot, as the reference's sample() returns
+    for tr in trs[300:340]:                                # 40 transitions: a third of the ring is rewritten
+        for b in bufs:
+            b.insert(tr)
+    assert any(lazy["observations"][k].packed is not None for k in keys), "no sampled window was hit: weak test"
+    agent = DrQLearner.create(0, obs_space, act_space, pixel_keys=keys, num_qs=2)
+    a1, i1 = agent.update(lazy, 2, pixel_keys=keys)
+    a2, i2 = agent.update(hostb, 2, pixel_keys=keys)
+    assert i1 == i2
+    assert torch.equal(a1.critic.store.flat, a2.critic.store.flat)
+
+
+def test_config5_large_batch_update_properties(dev):
+    """BASELINE config 5's per-GPU shape on one GPU: batch 4096, UTD 1 (2 x 128^2 cameras, stack 3, 10/2 critics).
+    The CPU oracle would need minutes, so size-independent properties (the pattern of
+    test_full_size_update_properties): augmented rows bit-exact vs the oracle's crop, a bit-identical repeat, the rng
+    chain, finite outputs; plus linearity of the loss scale: critic_loss / q of the 4096-row step equal the row-weighted
+    mean of the same quantities over its 16 contiguous 256-row slices evaluated at the same parameters."""
+    from oracle import learner as ol
+    from oracle import prng as oprng
+    from serl_amd.agents import DrQLearner
+    from serl_amd.data import MemoryEfficientReplayBuffer
+    from helpers import rollout_transitions
+    keys = ("wrist_1", "wrist_2")
+    H = W = 128; S = 3; B, U = 4096, 1
+    n = B * U
+    obs_space, act_space = pixel_spaces(keys, H, W, S, 19, 7)
+    bufs = [MemoryEfficientReplayBuffer(obs_space, act_space, 1500, pixel_keys=keys, device=d) for d in (None, "cuda")]
+    rng = np.random.default_rng(6)
+    for tr in rollout_transitions(rng, 1200, keys, H, W, S, 19, 7, episode_len=100):
+        for b in bufs:
+            b.insert(tr)
+    args = dict(batch_size=n, pack_obs_and_next_obs=True, demo_batch_size=n // 2, demo_size=300)
+    for b in bufs:
+        b.seed(4)
+    lazy = next(bufs[1].get_iterator(queue_size=1, sample_args=args))
+    host = bufs[0].sample(**args)
+    kw = dict(pixel_keys=keys, cnn_features=(32, 64, 128, 256), cnn_filters=(3, 3, 3, 3), cnn_strides=(2, 2, 2, 2),
+              latent_dim=64, num_qs=10, num_min_qs=2, critic_layer_norm=True, backup_entropy=False, init_temperature=0.1)
+    agent = DrQLearner.create(9, obs_space, act_space, **kw)
+    a1, i1 = agent.update(lazy, U, pixel_keys=keys)
+    rows = np.arange(0, n, 61)
+    ws = a1._ws(B)
+    r, key = oprng.split(agent.rng)
+    for side, sl in (("obs", slice(0, S)), ("next", slice(1, S + 1))):
+        kk = key
+        for cam in keys:
+            kcam, kk = oprng.split(kk)
+            offs = ol.crop_offsets_fast(kcam, n)[rows]
+            want = ol.random_crop_batch(host["observations"][cam][rows][..., sl], offs)
+            got = ws.tensor(f"aug_{side}_{cam}", (n, H, W, 3 * S), torch.uint8)[torch.as_tensor(rows, device=dev)]
+            assert np.array_equal(got.cpu().numpy().reshape(len(rows), H, W, 3, S), want), f"aug {side} {cam}"
+        r, key = oprng.split(r)
+    a2, i2 = agent.update(lazy, U, pixel_keys=keys)
+    assert i1 == i2, (i1, i2)
+    for name in ("actor", "critic", "target_critic"):
+        assert torch.equal(getattr(a1, name).store.flat, getattr(a2, name).store.flat), name
+    e = agent.rng
+    e, _ = oprng.split(e)
+    e, _ = oprng.split(e)
+    for _ in range(4 * U + 2):
+        _, e = oprng.split(e)
+    assert np.array_equal(a1.rng, e)
+    assert all(np.isfinite(v) for v in i1.values())
+    assert bool(torch.isfinite(a1.critic.store.flat).all()) and bool(torch.isfinite(a1.actor.store.flat).all())
+
+
+# Free-running drift bounds (relative, per logged scalar and call, against the float64 oracle over the same calls).
+# north_star's bar is 1e-3.  It holds at precision "highest" for both shapes and at "bf16_3x" for the state shape.  For
+# the pixel shape at "bf16_3x" it holds per call (test_drq_learner_matches_oracle: oracle re-synchronised before each
+# call) but NOT free-running: measured 5e-3 after the first call (2 Adam steps) and 2.5e-2 (q) / 5.1e-2 (actor_loss)
+# after 12 Adam steps at batch 8, against 2e-5 / 5.5e-4 for the float32 oracle (gpurun_out/free_running_drift_*.json,
+# copied to profiles/).  A bf16_3x product is accurate to ~2^-17, i.e. ~128x coarser than fp32: ~128x more
+# pre-activations land on the other side of a ReLU (gradient error ~ sqrt of that fraction), and Adam's first, sign-like
+# steps turn every sign flip of a near-zero gradient entry into a 2*lr parameter difference.  The bound asserted for that
+# case is 2x the measured drift: a regression guard, not a parity claim.
+DRIFT_BOUND = {("c2_state", "highest"): 1e-3, ("c2_state", "bf16_3x"): 1e-3,
+               ("c3_pixel", "highest"): 1e-3, ("c3_pixel", "bf16_3x"): 1e-1}
+
+
+@pytest.mark.parametrize("shape", ["c2_state", "c3_pixel"])
+def test_free_running_drift(dev, shape, prec):
+    """north_star's tolerance ("rel 1e-3 on losses and Q after N steps with a fixed RNG stream"), measured: N = 6
+    consecutive update() calls with NO re-synchronisation of the oracle, at both matmul precisions, next to the drift of
+    the float32 oracle against the float64 oracle over the same calls (two correct implementations of the same
+    update).  Bounds: DRIFT_BOUND above.  The measured numbers go to gpurun_out/free_running_drift_<shape>_<prec>.json
+    (quoted in DESIGN.md 5)."""
+    import json
+    import os
+    from oracle import learner as ol
+    rng = np.random.default_rng(12)
+    N = 6
+    if shape == "c2_state":        # BASELINE config 2 networks; UTD shortened to 4 for the CPU oracle (24 Adam steps)
+        from serl_amd.agents import SACLearner
+        obs_space, act_space = state_spaces(17, 6)
+        agent = SACLearner.create(42, obs_space, act_space, num_qs=10, num_min_qs=2, critic_layer_norm=True,
+                                  backup_entropy=False, init_temperature=0.1)
+        B, U = 256, 4
+        mk = lambda: make_state_batch(rng, B * U, 17, 6)
+        oupd = lambda st, cfg, b, dt: ol.sac_update(st, cfg, b, U, dtype=dt)
+        upd = lambda a, b: a.update(b, U)
+    else:                          # BASELINE config 3 shapes (2 x 128^2, stack 3, E1 encoder, 10/2 critics), batch 8, UTD 2
+        from serl_amd.agents import DrQLearner
+        keys = ("wrist_1", "wrist_2")
+        H = W = 128; S = 3; B, U = 8, 2
+        obs_space, act_space = pixel_spaces(keys, H, W, S, 19, 7)
+        agent = DrQLearner.create(42, obs_space, act_space, pixel_keys=keys, cnn_features=(32, 64, 128, 256),
+                                  cnn_filters=(3, 3, 3, 3), cnn_strides=(2, 2, 2, 2), latent_dim=64, num_qs=10,
+                                  num_min_qs=2, critic_layer_norm=True, backup_entropy=False, init_temperature=0.1)
+        mk = lambda: make_pixel_batch(rng, B * U, keys, H, W, S, 19, 7, packed=True)
+        oupd = lambda st, cfg, b, dt: ol.drq_update(st, cfg, b, U, dtype=dt)
+        upd = lambda a, b: a.update(b, U, pixel_keys=keys)
+    o32, ocfg = agent_to_oracle(agent)
+    o64, _ = agent_to_oracle(agent)
+    rel = lambda a, b: abs(float(a) - float(b)) / max(abs(float(b)), 1e-2)
+    rows = []
+    for it in range(N):
+        batch = mk()
+        o64, i64 = oupd(o64, ocfg, batch, torch.float64)
+        o32, i32 = oupd(o32, ocfg, batch, torch.float32)
+        agent, info = upd(agent, batch)
+        rows.append({"call": it + 1, "adam_steps": (it + 1) * U,
+                     "product_vs_f64": {k: rel(info[k], i64[k]) for k in i64},
+                     "f32_oracle_vs_f64": {k: rel(i32[k], i64[k]) for k in i64}})
+        assert np.array_equal(agent.rng, o64["rng"])
+    worst_p = max(max(r["product_vs_f64"].values()) for r in rows)
+    worst_o = max(max(r["f32_oracle_vs_f64"].values()) for r in rows)
+    out = {"shape": shape, "precision": prec, "calls": N, "utd": U, "batch": B, "worst_product_vs_f64": worst_p,
+           "worst_f32_oracle_vs_f64": worst_o, "rows": rows}
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(os.path.join("gpurun_out", f"free_running_drift_{shape}_{prec}.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print(f"free-running drift {shape} {prec}: product {worst_p:.3e}  fp32-oracle {worst_o:.3e}")
+    bound = DRIFT_BOUND[(shape, prec)]
+    for r in rows:
+        for k, v in r["product_vs_f64"].items():
+            assert v <= max(bound, 4.0 * r["f32_oracle_vs_f64"][k]), \
+                f"call {r['call']} {k}: product drift {v:.3e} > {bound:.1e} (fp32 oracle {r['f32_oracle_vs_f64'][k]:.3e})"
