@@ -57,9 +57,9 @@ def test_wgrad_noalloc_matches_workspace_variant(dev):
     assert n2 < n1 <= limit
     _case(dev, ops, rng, 2, 4, 128, 9, 32, True)          # uint8 first layer
     # beyond the array: rejected with a clear error, nothing launched
-    big = ops.conv2d_wgrad_workspace_bytes(8, 256, 31, 31, 64, 3, 3, 2, 128)
+    big = ops.conv2d_wgrad_workspace_bytes(8, 64, 15, 15, 256, 3, 3, 2, 512)
     assert big > limit
     d = torch.zeros(16, device=dev)
-    with pytest.raises(ValueError, match="available"):
+    with pytest.raises(ValueError, match="67108864 available"):
         ops.convs_wgrad_noalloc([d.data_ptr()] * 8, [d.data_ptr()] * 8, [d.data_ptr()] * 8, [d.data_ptr()] * 8, False,
-                                256, 31, 31, 64, 3, 3, 2, 128, ops.current_stream())
+                                64, 15, 15, 256, 3, 3, 2, 512, ops.current_stream())
