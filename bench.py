@@ -206,9 +206,12 @@ def main():
         agent, info = agent.update(b, UTD, pixel_keys=KEYS)
     torch.cuda.synchronize()
     progress("warm-up done")
+    native = agent._native
     timer = None
-    if not args.no_kernel_timer:
-        timer = ops.TIMER = ops.KernelTimer()
+    if not args.no_kernel_timer:      # HIP events around every conv launch, recorded by the driver on the launch stream
+        timer = native
+        native.timing_reset()
+        native.set_timing(conv_events=True)
     barrier()
     t0 = time.perf_counter()
     for b in batches[args.warmup:]:
@@ -216,7 +219,7 @@ def main():
     host_enqueue = time.perf_counter() - t0           # update() does not wait for the GPU: this is pure launch time
     barrier()
     elapsed = time.perf_counter() - t0
-    ops.TIMER = None
+    native.set_timing(conv_events=False)
     progress(f"timed region done: {elapsed / args.steps * 1e3:.2f} ms/step")
     # end to end: the same loop with the host-side index draw, rejection resampling and H2D of the small leaves inside
     # it (the iterator samples batch i+1 while the GPU runs update i: update() does not block the host)
@@ -228,14 +231,17 @@ def main():
             agent, info = agent.update(next(it), UTD, pixel_keys=KEYS)
         barrier()
         e2e = time.perf_counter() - t0
+    conv_records = native.conv_timings() if timer is not None else []
     if args.phases and rank == 0:
-        ops.PHASES = marks = []
+        native.timing_reset()
+        native.set_timing(phase_events=True)
         agent.update(batches[-1], UTD, pixel_keys=KEYS)
         torch.cuda.synchronize()
-        ops.PHASES = None
+        native.set_timing()
+        marks = native.phase_timings()
         acc = {}
-        for (n0, e0), (n1, e1) in zip(marks[:-1], marks[1:]):
-            acc.setdefault(f"{n0}->{n1}", []).append(e0.elapsed_time(e1))
+        for (n0, ms), (n1, _) in zip(marks[:-1], marks[1:]):
+            acc.setdefault(f"{n0}->{n1}", []).append(ms)
         for k, v in acc.items():
             print(f"phase {k:28s} n={len(v):3d} mean {sum(v) / len(v) * 1e3:8.1f} us  total {sum(v):7.2f} ms",
                   file=sys.stderr)
@@ -277,7 +283,13 @@ def main():
         # A kernel (one template instantiation, as rocprofv3 lists it) is launched with different group counts: the
         # target + critic passes (4 groups) on the main stream, the actor's run-ahead pass (2 groups) on its own.
         # Dominant kernel = largest total time over all its launches; figures are per launch, averaged over them.
-        summ = timer.summary()
+        summ = {}
+        for key, ms_, fl_, by_ in conv_records:
+            if precision == "highest":
+                key = (key[0].replace("convs_", "conv2d_"),) + key[1:]
+            e = summ.setdefault(key, [0, 0.0, fl_, by_])
+            e[0] += 1; e[1] += ms_
+        summ = {k: (v[0], v[1] / v[0], v[2], v[3]) for k, v in summ.items()}
         fams = {}
         for k, (n_, ms_, fl_, by_) in summ.items():
             f = fams.setdefault(k[:2] + k[3:], dict(n=0, t=0.0, fl=0.0, by=0.0, tr=0.0, tr_ok=True, src=None, groups=[]))

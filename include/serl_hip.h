@@ -185,6 +185,79 @@ int serl_prng_split(unsigned k0, unsigned k1, int num, unsigned* out);
 int serl_prng_bits(unsigned k0, unsigned k1, int n, unsigned* out);
 int serl_prng_choice(unsigned k0, unsigned k1, int n, int m, int* out);
 
+/* ==== Native step driver: one call per update() / per action (serl_amd/csrc/driver.hip).
+ * The coarse boundary of SURVEY.md 8(b): Python holds handles and pointers, every launch, stream, event and per-step
+ * scalar (jax split chain, REDQ member strides, Adam bias corrections) of
+ *   SACLearner.update    serl/agents/sac/sac_learner.py:221-238 (update_critic :160-219, update_actor :120-144,
+ *                        update_temperature :146-158)
+ *   DrQLearner.update    serl/agents/drq/drq_learner.py:154-186 (+ _unpack / random crop, utils/commons.py:7-29,
+ *                        utils/augmentations.py:5-11,44-48) and PixelDDPGLearner.update (ddpg/pixel_ddpg_learner.py:148-181)
+ *   Agent.sample_actions / eval_actions   serl/agents/agent.py:12-37
+ * is produced in C.  serl_learner_create allocates host state, HIP streams and events; device workspace buffers
+ * (activations etc.) are allocated by the handle on first use of a minibatch size and freed by serl_learner_destroy.
+ * One handle serves one learner thread (update) and any number of acting threads (act, serialised internally). */
+typedef struct serl_learner serl_learner;
+typedef struct {
+  int action_dim, num_hidden, hidden_dims[4], num_qs;
+  int num_min_qs;              /* 0 = None (no REDQ subsample) */
+  int critic_layer_norm, backup_entropy;
+  int has_temperature;         /* 0: DDPG variants (no entropy term: temp[0] = -inf, no temperature step) */
+  int pixel, obs_dim;          /* state-based learners: pixel = 0, observations (n, obs_dim) */
+  int num_cameras, height, width, stack, state_dim, latent_dim, num_conv;
+  int cnn_features[8], cnn_filters[8], cnn_strides[8];
+  int aug_rank[4];             /* position of the i-th camera (sorted-key order) in the caller's pixel_keys order */
+  float discount, tau, target_entropy, actor_lr, critic_lr, temp_lr;
+} serl_learner_config;
+/* flat fp32 device buffers of ONE agent copy (parameters, Adam moments, temperature state {log_temp, mu, nu}) plus the
+ * gradient buffers (same layouts); update() steps them in place -- the caller clones first to keep the old agent valid */
+typedef struct {
+  float *actor, *actor_mu, *actor_nu, *critic, *critic_mu, *critic_nu, *target, *temp, *critic_grads, *actor_grads;
+  int actor_step, critic_step, temp_step;   /* optimizer step counts BEFORE this update */
+} serl_agent_buffers;
+typedef struct {
+  int kind;                          /* 0 device frame store + window indices, 1 packed (n,H,W,3,S+1), 2 unpacked */
+  const unsigned char* frames; long long capacity; const long long* indx;   /* kind 0 */
+  const unsigned char* obs;          /* kind 1: the packed tensor; kind 2: observations (n,H,W,3,S) */
+  const unsigned char* next_obs;     /* kind 2: next_observations (n,H,W,3,S) */
+} serl_pixel_source;
+typedef struct {
+  int n;                             /* rows = minibatch * utd_ratio (this rank's rows) */
+  int aug_mode;                      /* 0 state-based, 1 DrQLearner key order, 2 PixelDDPGLearner key order */
+  const float *actions, *rewards, *masks;
+  const float *obs, *next_obs;       /* state-based */
+  const float *state, *next_state;   /* pixel-based */
+  serl_pixel_source pixels[4];       /* cameras in sorted-key order */
+} serl_update_batch;
+/* data-parallel hook: sum buffer `which` over the ranks (0 critic_grads, 1 actor_grads, 2 the first 4 info floats --
+ * serl_learner_update passes info_out for those), behind the work enqueued on the update's stream; returns 0 on success */
+typedef int (*serl_allreduce_fn)(void* ctx, int which);
+/* critic_offsets / actor_offsets: offsets in floats of every leaf of the flat stores in the layout order of
+ * serl_amd/networks/spec.py (encoder + trunk leaves first for pixel learners), followed by the store's total size */
+int serl_learner_create(const serl_learner_config* cfg, const long long* critic_offsets, int n_critic,
+                        const long long* actor_offsets, int n_actor, serl_learner** out);
+int serl_learner_destroy(serl_learner* h);
+/* rng_in / rng_out: jax key (uint32[2]) before / after the call; info_out: 8 device floats {critic loss sum, q sum,
+ * actor loss sum, logp sum, temperature, temperature loss, entropy, -}; everything is enqueued on `stream` and the
+ * handle's own streams, nothing waits for the GPU */
+int serl_learner_update(serl_learner* h, const serl_agent_buffers* agent, const serl_update_batch* batch, int utd_ratio,
+                        const unsigned* rng_in, unsigned* rng_out, float* info_out, void* stream,
+                        serl_allreduce_fn allreduce, void* allreduce_ctx, int rank, int world);
+/* images: per camera (sorted order) a device (H,W,3*S) uint8 image; state_or_obs: device state / observation vector;
+ * key NULL or deterministic != 0: mode of the policy; act_out / eps_out (may be NULL): device, action_dim floats */
+int serl_learner_act(serl_learner* h, const float* actor_params, const unsigned char* const* images,
+                     const float* state_or_obs, const unsigned* key, int deterministic, float* act_out, float* eps_out,
+                     void* stream);
+/* test / tooling access: copy a named workspace buffer of the update at minibatch size B ("aug_<0 obs|1 next>_<cam>") */
+int serl_learner_read_buffer(serl_learner* h, int B, const char* name, void* dst, long long nbytes, void* stream);
+long long serl_learner_workspace_bytes(serl_learner* h);
+/* bench.py instrumentation: HIP events around every conv launch (on its launch stream) / between the phases of a step */
+int serl_learner_set_timing(serl_learner* h, int conv_events, int phase_events);
+int serl_learner_timing_count(serl_learner* h);
+int serl_learner_timing_get(serl_learner* h, int i, int* desc, double* val);
+int serl_learner_phase_count(serl_learner* h);
+int serl_learner_phase_get(serl_learner* h, int i, const char** name, double* ms_to_next);
+int serl_learner_timing_reset(serl_learner* h);
+
 #ifdef __cplusplus
 }
 #endif

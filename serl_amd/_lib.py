@@ -67,12 +67,24 @@ _SIGS = {
     "serl_crop_offsets": [c_u, c_u, c_i, c_i, c_i, c_i, c_p, c_p],
     "serl_prng_randint": [c_u, c_u, c_i, c_i, c_i, c_p, c_p, c_p],
     "serl_take_rows": [c_p, c_ll, c_ll, c_p, c_p, c_i, c_p],
+    "serl_learner_create": [c_p, c_p, c_i, c_p, c_i, c_p],
+    "serl_learner_destroy": [c_p],
+    "serl_learner_update": [c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i],
+    "serl_learner_act": [c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p],
+    "serl_learner_read_buffer": [c_p, c_i, C.c_char_p, c_p, c_ll, c_p],
+    "serl_learner_workspace_bytes": [c_p],
+    "serl_learner_set_timing": [c_p, c_i, c_i],
+    "serl_learner_timing_count": [c_p],
+    "serl_learner_timing_get": [c_p, c_i, c_p, c_p],
+    "serl_learner_phase_count": [c_p],
+    "serl_learner_phase_get": [c_p, c_i, c_p, c_p],
+    "serl_learner_timing_reset": [c_p],
     "serl_prng_split": [c_u, c_u, c_i, c_p],
     "serl_prng_bits": [c_u, c_u, c_i, c_p],
     "serl_prng_choice": [c_u, c_u, c_i, c_i, c_p],
 }
 _RESTYPE = {"serl_conv2d_wgrad_workspace_bytes": c_ll, "serl_convs_weight_bytes": c_ll,
-            "serl_convs_wgrad_noalloc_max_bytes": c_ll}
+            "serl_convs_wgrad_noalloc_max_bytes": c_ll, "serl_learner_workspace_bytes": c_ll}
 
 EXPORTS = tuple(_SIGS) + ("serl_last_error",)
 

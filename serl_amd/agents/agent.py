@@ -11,8 +11,6 @@ import numpy as np
 import torch
 
 from .. import ops, prng
-from ..networks import modules as nn
-from ..networks.modules import Workspace
 
 
 class Agent:
@@ -28,34 +26,31 @@ class Agent:
 
     # ------------------------------------------------------------------ acting
     def _act(self, observations, key, deterministic, want_eps=False):
+        """One policy evaluation on a single, un-batched observation: one call into the native driver
+        (serl_learner_act: encoder, trunk, TanhNormal head), one small D2H copy of the action."""
         cfg = self._cfg
         dev = self.actor.store.flat.device
-        ws: Workspace = self._shared.setdefault("ws_act", Workspace(dev))
-        st = ops.current_stream()
         A = cfg.action_dim
-        ldz = cfg.latent + A
-        z = ws.ptr("zA", (1, ldz))
-        if cfg.pixel:
-            imgs = []
-            for cam in cfg.cams:
-                x = np.ascontiguousarray(np.asarray(observations[cam], dtype=np.uint8)).reshape(
-                    1, cfg.H, cfg.W, 3 * cfg.stack)                      # (H,W,3,S) -> channel c*S+s
-                t = ws.tensor(f"img_{cam}", x.shape, torch.uint8)
-                t.copy_(torch.from_numpy(x), non_blocking=False)
-                imgs.append(t.data_ptr())
-            s = ws.tensor("state", (1, cfg.state_dim))
-            s.copy_(torch.from_numpy(np.asarray(observations["state"], dtype=np.float32).reshape(1, -1)))
-            nn.encoder_fwd(cfg, [("A", self.actor.store, imgs)], 1, ws, st)
-            nn.trunk_fwd(cfg, "A", self.actor.store, s.data_ptr(), z, ldz, 1, ws, st, save=False)
-        else:
-            zt = ws.tensor("zA", (1, ldz))
-            zt[:, :cfg.obs_dim].copy_(torch.from_numpy(np.asarray(observations, dtype=np.float32).reshape(1, -1)))
-        act = ws.tensor("act", (1, A))
-        nn.policy_fwd(cfg, "A", self.actor.store, z, ldz, 1, ws, st, key, 0, 1, act.data_ptr(), A,
-                      deterministic=deterministic, save=want_eps, want_logp=False)
+        imgs, keep = None, []
+        with torch.cuda.device(dev):
+            if cfg.pixel:
+                imgs = []
+                for cam in cfg.cams:
+                    x = np.ascontiguousarray(np.asarray(observations[cam], dtype=np.uint8)).reshape(
+                        cfg.H, cfg.W, 3 * cfg.stack)                         # (H,W,3,S) -> channel c*S+s
+                    t = torch.from_numpy(x).to(dev)
+                    keep.append(t)
+                    imgs.append(t.data_ptr())
+                s = torch.from_numpy(np.asarray(observations["state"], dtype=np.float32).reshape(-1)).to(dev)
+            else:
+                s = torch.from_numpy(np.asarray(observations, dtype=np.float32).reshape(-1)).to(dev)
+            out = torch.empty(2 * A, dtype=torch.float32, device=dev)          # [action | eps]
+            self._shared["native"].act(self.actor.store.base, imgs, s.data_ptr(), key, deterministic, out.data_ptr(),
+                                       out.data_ptr() + 4 * A if want_eps else None, ops.current_stream())
+            host = out.cpu().numpy()
         if want_eps:                 # the standard-normal draw behind the sample (DDPGLearner's exploration noise)
-            return act.cpu().numpy()[0], ws.tensor("eps_A", (1, A)).cpu().numpy()[0]
-        return act.cpu().numpy()[0]
+            return host[:A], host[A:]
+        return host[:A]
 
     def eval_actions(self, observations) -> np.ndarray:
         """mode of the policy = tanh(mean) (agent.py:19-22,29-31)."""

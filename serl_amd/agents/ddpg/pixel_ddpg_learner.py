@@ -13,7 +13,6 @@ from typing import Optional, Sequence, Tuple
 
 import torch
 
-from ... import prng
 from ..drq.drq_learner import DrQLearner
 from ..train_state import TempState
 from .ddpg_learner import DDPGLearner
@@ -38,9 +37,8 @@ class PixelDDPGLearner(DrQLearner):
         self.temp = TempState(torch.tensor([float("-inf"), 0.0, 0.0], dtype=torch.float32, device=dev), 0, 0.0)
         return self
 
-    def _aug_keys(self):
-        key_obs, rng = prng.split(self.rng)                                   # :169
-        key_next, rng = prng.split(rng)                                       # :171
-        return key_obs, key_next, self.rng                                    # :180 runs on new_agent: rng not replaced
+    # key, rng = split(rng) for the two augmentation keys (:169,171), and the DDPG update runs on new_agent, whose rng
+    # was never replaced (:180): evaluated by the native driver (aug_mode 2, driver.hip serl_learner_update)
+    _AUG_MODE = 2
 
     sample_actions = DDPGLearner.sample_actions

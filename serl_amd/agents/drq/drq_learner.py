@@ -6,7 +6,9 @@ update(batch, utd_ratio, pixel_keys):
   3. random-shift augmentation of obs and next_obs, whole B*U batch, per-camera keys  (:174-177, :131-137)
   4. SACLearner.update on the augmented batch         (:186)
 Steps 1 and 3 (and, for device-resident replay batches, the frame-stack gather of
-MemoryEfficientReplayBuffer.sample) are ONE HIP kernel per camera and side (gather_crop.hip).
+MemoryEfficientReplayBuffer.sample) are ONE HIP kernel per camera and side (gather_crop.hip), launched -- like
+everything else of the call -- by the native step driver (driver.hip); this module resolves the batch's pixel leaves
+(lazy frame windows / packed / unpacked, host or device) into device pointers.
 """
 from __future__ import annotations
 
@@ -15,17 +17,16 @@ from typing import Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-from ... import ops, prng
 from ...data.device_batch import FrameWindows
-from ...networks import modules as nn
+from ...native import KIND_FRAMES, KIND_PACKED, KIND_UNPACKED, UpdateBatch
 from ...networks.spec import NetConfig
 from ...spaces import is_dict
 from ..sac.sac_learner import SACLearner, _to_dev
 
-PAD = 4   # batched_random_crop(..., padding=4), serl/utils/augmentations.py:44
-
 
 class DrQLearner(SACLearner):
+    _AUG_MODE = 1      # rng, key = split(rng): the augmentation key is child 1 and the rng advances (drq_learner.py:174-177)
+
     @classmethod
     def create(cls, seed: int, observation_space, action_space, actor_lr: float = 3e-4, critic_lr: float = 3e-4,
                temp_lr: float = 3e-4, cnn_features: Sequence[int] = (32, 32, 32, 32),
@@ -65,116 +66,41 @@ class DrQLearner(SACLearner):
                         cnn_features=tuple(cnn_features), cnn_filters=tuple(cnn_filters),
                         cnn_strides=tuple(cnn_strides), latent_dim=int(latent_dim))
 
-    # ------------------------------------------------------------------ augmentation + unpack + gather
-    def _augment(self, batch, n, utd_ratio, key_obs, key_next, ws):
-        """Returns ({'obs'|'next': [u8 (n,H,W,3S) device tensor per camera in cfg.cams order]}, crop) where
-        crop(lo, rows, stream) launches the fused gather + _unpack + random-shift kernels for rows [lo, lo+rows)
-        of every (side, camera); the per-row offsets are computed here, for all rows.
-        data_augmentation_fn: per pixel key (caller order) key, rng = split(rng); crop with `key`."""
+    # ------------------------------------------------------------------ pixel leaves -> device pointers
+    def _pixel_sources(self, batch, n, ub: UpdateBatch, keep):
+        """Fill ub.pixels (cameras in sorted order).  A leaf is a lazy FrameWindows of a device replay buffer (or the
+        packed tensor it was pinned to before an insert overwrote its rows), a packed (n,H,W,3,S+1) array when the key
+        is absent from next_observations (`_unpack`), or unpacked obs / next_obs arrays; host arrays are uploaded."""
         cfg = self._cfg
         dev = self.actor.store.flat.device
-        st = ops.current_stream()
         H, W, S = cfg.H, cfg.W, cfg.stack
-        dist = self._dist
-        world = dist.world_size if dist is not None else 1
-        rank = dist.rank if dist is not None else 0
-        out = {"obs": {}, "next": {}}
-        jobs, lazy = [], []
         obs, nxt = batch["observations"], batch["next_observations"]
-        img = H * W * 3 * S
-        for side, rng, t0 in (("obs", key_obs, 0), ("next", key_next, 1)):
-            for cam in cfg.pixel_keys:                                   # augmentation key order = pixel_keys
-                key, rng = prng.split(rng)
-                off = ws.tensor(f"off_{side}_{cam}", (n, 2), torch.int32)
-                if world == 1:
-                    ops.crop_offsets(key, n, 0, n, PAD, off.data_ptr(), st)
-                else:                                                    # global-index keyed (SURVEY 8e)
-                    U = utd_ratio
-                    B = n // U
-                    for i in range(U):
-                        ops.crop_offsets(key, B, i * B * world + rank * B, n * world, PAD,
-                                         off.data_ptr() + 8 * i * B, st)
-                dst = ws.tensor(f"aug_{side}_{cam}", (n, H, W, 3 * S), torch.uint8)
-                packed = cam not in nxt
-                src = obs[cam] if (side == "obs" or packed) else nxt[cam]
-                if isinstance(src, FrameWindows) and src.packed is not None:
-                    src = src.packed              # an insert() hit this batch's rows before the gather: snapshot taken then
-                if isinstance(src, FrameWindows):
-                    lazy.append(src)
+        lazy = []
 
-                    def job(lo, rows, stream, src=src, off=off, dst=dst, t0=t0):
-                        ops.gather_crop_frames(src.frames.data_ptr(), src.capacity, src.indx.data_ptr() + 8 * lo, S + 1,
-                                               t0, off.data_ptr() + 8 * lo, dst.data_ptr() + lo * img, rows, H, W, S,
-                                               PAD, stream)
-                else:
-                    T = S + 1 if packed else S
-                    if isinstance(src, torch.Tensor):
-                        s_dev = src.to(dev).contiguous()
-                    else:
-                        s_dev = ws.tensor(f"h2d_{side if not packed else 'pk'}_{cam}", (n, H, W, 3, T), torch.uint8)
-                        if side == "obs" or not packed:
-                            s_dev.copy_(torch.from_numpy(np.ascontiguousarray(src)))
-                    assert tuple(s_dev.shape) == (n, H, W, 3, T), f"{cam}: {tuple(s_dev.shape)} != {(n, H, W, 3, T)}"
-
-                    def job(lo, rows, stream, s_dev=s_dev, off=off, dst=dst, T=T, t0=(t0 if packed else 0)):
-                        ops.gather_crop_packed(s_dev.data_ptr() + lo * H * W * 3 * T, T, t0, off.data_ptr() + 8 * lo,
-                                               dst.data_ptr() + lo * img, rows, H, W, S, PAD, stream)
-                jobs.append(job)
-                out[side][cam] = dst
-
-        def crop(lo, rows, stream):
-            for job in jobs:
-                job(lo, rows, stream)
-            if lo + rows >= n:       # every row's gather is enqueued: later inserts are ordered behind it by the stream
-                for fw in lazy:
-                    fw.consumed = True
-        return out, crop
-
-    def _prepare(self, batch, n):
-        raise RuntimeError("DrQLearner prepares features inside update()")
-
-    def _features(self, passes, feats, lo, B, ws, st, save_tag=None, trunk_streams=None, fork=None, prep=True,
-                  z_ptrs=None):
-        cfg = self._cfg
-        ldz = cfg.latent + cfg.action_dim
-        img_bytes = cfg.H * cfg.W * 3 * cfg.stack
-        enc_passes = []
-        for tag, store, which in passes:
-            imgs = [feats["aug"][which][cam].data_ptr() + lo * img_bytes for cam in cfg.cams]
-            enc_passes.append((tag, store, imgs))
-        nn.encoder_fwd(cfg, enc_passes, B, ws, st, mask_tag=save_tag, prep=prep)
-        if fork is not None:          # the trunks of the passes are independent: side streams wait for the encoders
-            fork.record(torch.cuda.current_stream())
-            for s_ in trunk_streams.values():
-                s_.wait_event(fork)
-        for tag, store, which in passes:
-            state = feats["next_state" if which == "next" else "state"]
-            st_ = trunk_streams[tag].cuda_stream if trunk_streams and tag in trunk_streams else st
-            z = z_ptrs[tag] if z_ptrs and tag in z_ptrs else ws.ptr(f"z{tag}", (B, ldz))
-            nn.trunk_fwd(cfg, tag, store, state.data_ptr() + 4 * lo * cfg.state_dim, z, ldz, B, ws, st_,
-                         save=(tag == save_tag))
-
-    def _features_bwd(self, tag, store, grads, feats, lo, B, ws, st, dz_ptr, lddz, need_encoder, gside=None,
-                      dz_slabs=(1, 0)):
-        cfg = self._cfg
-        ldz = cfg.latent + cfg.action_dim
-        which = "obs"
-        state = feats["state"]
-        nn.trunk_bwd(cfg, tag, store, grads, state.data_ptr() + 4 * lo * cfg.state_dim, ws.ptr(f"z{tag}", (B, ldz)),
-                     ldz, dz_ptr, lddz, B, ws, st, need_denc=need_encoder, gside=gside, dz_slabs=dz_slabs)
-        if need_encoder:
-            img_bytes = cfg.H * cfg.W * 3 * cfg.stack
-            imgs = [feats["aug"][which][cam].data_ptr() + lo * img_bytes for cam in cfg.cams]
-            nn.encoder_bwd(cfg, tag, store, grads, imgs, B, ws, st, gside=gside, use_masks=True)
+        def dev_u8(x, T):
+            t = x if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(x))
+            t = t.to(dev).contiguous()
+            assert t.dtype == torch.uint8 and tuple(t.shape) == (n, H, W, 3, T), f"{tuple(t.shape)} != {(n, H, W, 3, T)}"
+            keep.append(t)
+            return t.data_ptr()
+        for ci, cam in enumerate(cfg.cams):
+            src = ub.pixels[ci]
+            leaf = obs[cam]
+            packed = cam not in nxt
+            if isinstance(leaf, FrameWindows) and leaf.packed is not None:
+                leaf = leaf.packed            # an insert() hit this batch's rows before the gather: snapshot taken then
+            if isinstance(leaf, FrameWindows):
+                assert leaf.num_stack == S and len(leaf) == n
+                src.kind, src.frames, src.capacity, src.indx = KIND_FRAMES, leaf.frames.data_ptr(), leaf.capacity, \
+                    leaf.indx.data_ptr()
+                lazy.append(leaf)
+            elif packed:
+                src.kind, src.obs = KIND_PACKED, dev_u8(leaf, S + 1)
+            else:
+                src.kind, src.obs, src.next_obs = KIND_UNPACKED, dev_u8(leaf, S), dev_u8(nxt[cam], S)
+        return lazy
 
     # ------------------------------------------------------------------ update
-    def _aug_keys(self):
-        """(key for obs, key for next_obs, rng the SAC update starts from).
-        rng, key = split(rng) -- note: rng is child 0 here (drq_learner.py:174,176)."""
-        rng, key_obs = prng.split(self.rng)
-        rng, key_next = prng.split(rng)
-        return key_obs, key_next, rng
-
     def update(self, batch, utd_ratio: int, pixel_keys=("pixels",)):
         cfg = self._cfg
         pixel_keys = tuple(pixel_keys)
@@ -184,14 +110,16 @@ class DrQLearner(SACLearner):
         assert n % utd_ratio == 0
         dev = self.actor.store.flat.device
         f32 = torch.float32
-        ws = self._ws(n // utd_ratio)
         # share the critic's encoder with the actor, once per call (drq_learner.py:171-172)
         actor = self.actor.clone()
         nenc = self.critic.store.layout.prefix_size("image_encoder")
         actor.store.flat[:nenc].copy_(self.critic.store.flat[:nenc])
-        key_obs, key_next, rng = self._aug_keys()
-        aug, crop = self._augment(batch, n, utd_ratio, key_obs, key_next, ws)
-        feats = dict(aug=aug, crop=crop,
-                     state=_to_dev(batch["observations"]["state"], dev, f32).reshape(n, cfg.state_dim),
-                     next_state=_to_dev(batch["next_observations"]["state"], dev, f32).reshape(n, cfg.state_dim))
-        return self.replace(rng=rng)._update_prepared(batch, feats, n, utd_ratio, actor)
+        ub = UpdateBatch()
+        keep = [_to_dev(batch["observations"]["state"], dev, f32).reshape(n, cfg.state_dim),
+                _to_dev(batch["next_observations"]["state"], dev, f32).reshape(n, cfg.state_dim)]
+        ub.state, ub.next_state = keep[0].data_ptr(), keep[1].data_ptr()
+        lazy = self._pixel_sources(batch, n, ub, keep)
+        out = self._run_update(batch, ub, n, utd_ratio, actor, self.rng, keep)
+        for fw in lazy:     # every row's gather is enqueued: later inserts are ordered behind it by the stream
+            fw.consumed = True
+        return out

@@ -1,0 +1,1236 @@
+// Native step driver: ONE C-ABI call enqueues a whole `update(batch, utd_ratio)` of the SAC / DrQ learners
+// (serl/agents/sac/sac_learner.py:221-238 with update_critic :160-219, update_actor :120-144, update_temperature
+// :146-158; serl/agents/drq/drq_learner.py:154-186) -- every kernel launch, all streams and events, the jax split chain
+// of the call, REDQ member strides and Adam bias corrections are computed here; Python passes pointers and gets the
+// new rng back.  The same for one `sample_actions` / `eval_actions` (serl/agents/agent.py:12-37).
+//
+// The launch sequence (what runs on which stream) is DESIGN.md section 3b:
+//   main   : gather+crop of all B*U rows, then per critic step: target + critic encoders (grouped launches), target
+//            trunk + ensemble, TD loss, critic backward (data-gradient chain), Adam + Polyak
+//   side 1 : critic trunk + ensemble forward of the step (next to the target chain)
+//   gside  : parameter-gradient kernels of the backward (column sums, dW GEMMs, conv weight gradients)
+//   actor  : the actor's no-grad pass over next_obs for step i+1 (its parameters are constant during the UTD loop),
+//            gated to start when main leaves its HBM-bound encoder forward; behind the last one, the actor's own pass
+//            over obs for the actor step
+// Host cost per launch is a plain function call + hipLaunchKernel (~3-5 us) instead of ~21 us of Python per launch.
+#include <math.h>
+
+#include <algorithm>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/serl_hip.h"
+#include "common.h"
+
+#define DRV(expr)            \
+  do {                       \
+    int e__ = (expr);        \
+    if (e__) return e__;     \
+  } while (0)
+#define DRV_HIP(expr) SERL_CHECK_HIP(expr, "learner")
+
+namespace {
+
+constexpr int TRUNK_DIM = 512;    // hard-coded in serl/networks/pixel_multiplexer.py:34
+constexpr int SLE_FEATURES = 8;   // two_d4pg_encoder.py:40
+constexpr int MAX_CAM = 4, MAX_CONV = 8, MAX_HID = 4, MAXG_ = 8;
+constexpr float ADAM_B1 = 0.9f, ADAM_B2 = 0.999f, ADAM_EPS = 1e-8f;   // optax.adam defaults
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2 };
+
+struct ConvL { int IH, IW, C, K, S, F, OH, OW; };
+
+struct Cfg {
+  int A, nh, hid[MAX_HID], E, num_min_qs, ln, backup_entropy, has_temp, pixel;
+  int obs_dim;                                   // state-based
+  int ncam, H, W, stack, state_dim, latent_dim;  // pixel-based
+  int nl; ConvL L[MAX_CONV];
+  int aug_rank[MAX_CAM];   // position of (sorted) camera ci in the caller's pixel_keys order: augmentation key order
+  float discount, tau, target_entropy, actor_lr, critic_lr, temp_lr;
+  int enc_dim, latent, ldz;
+};
+
+// offsets (in floats) of the leaves of a flat parameter store, in the order serl_amd/networks/spec.py adds them
+struct EncOff { long long ck[MAX_CAM][MAX_CONV], cb[MAX_CAM][MAX_CONV], sle[MAX_CAM], d0k, d0b, l0s, l0b, d1k, d1b, l1s, l1b; };
+struct CriticOff { EncOff e; long long w[MAX_HID], b[MAX_HID], lns[MAX_HID], lnb[MAX_HID], hk, hb; long long size; };
+struct ActorOff { EncOff e; long long w[MAX_HID], b[MAX_HID], mk, lk, mb, lb; long long size; };
+
+struct Store {   // a flat fp32 parameter (or gradient) buffer
+  float* base;
+  float* at(long long off) const { return base + off; }
+};
+
+// ---------------------------------------------------------------- named, lazily allocated device buffers
+struct Workspace {
+  struct Buf { void* p; size_t bytes; };
+  std::unordered_map<std::string, Buf> m;
+  char name[96];
+
+  int get(size_t bytes, void** out, hipStream_t st) {
+    auto it = m.find(name);
+    if (it != m.end() && it->second.bytes == bytes) { *out = it->second.p; return SERL_OK; }
+    if (it != m.end()) {   // shape of a name changed: rare (another batch size reuses the handle's act workspace)
+      DRV_HIP(hipDeviceSynchronize());
+      DRV_HIP(hipFree(it->second.p));
+      m.erase(it);
+    }
+    void* p = nullptr;
+    DRV_HIP(hipMalloc(&p, bytes ? bytes : 4));
+    // zero fill; the buffer may be used on any of the driver's streams: wait for the fill once, on first use of a name
+    DRV_HIP(hipMemsetAsync(p, 0, bytes ? bytes : 4, st));
+    DRV_HIP(hipStreamSynchronize(st));
+    m[name] = Buf{p, bytes};
+    *out = p;
+    return SERL_OK;
+  }
+  void release() {
+    for (auto& kv : m) (void)hipFree(kv.second.p);
+    m.clear();
+  }
+};
+#define WSF(ws, st, var, nfloats, ...)                                   \
+  float* var = nullptr;                                                  \
+  {                                                                      \
+    snprintf((ws).name, sizeof((ws).name), __VA_ARGS__);                 \
+    DRV((ws).get((size_t)(nfloats) * 4, (void**)&var, st));              \
+  }
+#define WSB(ws, st, type, var, nbytes, ...)                              \
+  type* var = nullptr;                                                   \
+  {                                                                      \
+    snprintf((ws).name, sizeof((ws).name), __VA_ARGS__);                 \
+    DRV((ws).get((size_t)(nbytes), (void**)&var, st));                   \
+  }
+
+// ---------------------------------------------------------------- optional HIP-event instrumentation (bench.py)
+struct TimeRec { int kind, in_u8, groups, B, IH, C, F; double flops, bytes; hipEvent_t a, b; };
+struct PhaseRec { const char* name; hipEvent_t ev; };
+
+struct GradSide {   // side stream for parameter-gradient kernels: fork() = side waits for main, join() = main waits
+  hipStream_t main = nullptr, side = nullptr, own = nullptr;   // own: the handle's side stream; side: the one in use
+  std::vector<hipEvent_t> ev;
+  size_t n = 0;
+  int next(hipEvent_t* e) {
+    if (n == ev.size()) {
+      hipEvent_t x;
+      DRV_HIP(hipEventCreateWithFlags(&x, hipEventDisableTiming));
+      ev.push_back(x);
+    }
+    *e = ev[n++];
+    return SERL_OK;
+  }
+  void begin(hipStream_t m, bool use_side) { main = m; side = use_side ? own : m; n = 0; }
+  int fork(hipStream_t* out) {
+    if (side == main) { *out = main; return SERL_OK; }
+    hipEvent_t e;
+    DRV(next(&e));
+    DRV_HIP(hipEventRecord(e, main));
+    DRV_HIP(hipStreamWaitEvent(side, e, 0));
+    *out = side;
+    return SERL_OK;
+  }
+  int join() {
+    if (side == main) return SERL_OK;
+    hipEvent_t e;
+    DRV(next(&e));
+    DRV_HIP(hipEventRecord(e, side));
+    DRV_HIP(hipStreamWaitEvent(main, e, 0));
+    return SERL_OK;
+  }
+};
+
+}  // namespace
+
+struct serl_learner {
+  Cfg cfg;
+  CriticOff co;
+  ActorOff ao;
+  int device = 0;
+  std::unordered_map<int, Workspace> ws_update;   // per minibatch size
+  Workspace ws_act;
+  std::mutex act_mu;
+  hipStream_t s1 = nullptr, astream = nullptr;
+  GradSide gside;
+  hipEvent_t fork_ev = nullptr, join1 = nullptr, astart = nullptr, agate = nullptr, aobs = nullptr;
+  std::vector<hipEvent_t> adone;
+  // instrumentation
+  bool timing = false, phases = false;
+  std::vector<TimeRec> trecs;
+  std::vector<PhaseRec> precs;
+};
+
+namespace {
+
+// ---------------------------------------------------------------- helpers mirroring serl_amd/ops.py
+struct G {   // serl_gemm arguments with the defaults of ops.gemm
+  const float* a; const float* b; float* c; const float* bias = nullptr;
+  int nb = 1, M = 0, N = 0, K = 0;
+  long long a_zs = 0, a_ms = 0, a_ks = 0, b_zs = 0, b_ks = 0, b_ns = 0, c_zs = 0, c_ms = 0, bias_zs = 0;
+  int seglen = 0; long long a_ss = 0, b_ss = 0;
+  int nsplit = 1; long long c_split = 0;
+  int relu = 0, acc = 0, a_kc = 1, b_nc = 1;
+};
+int gemm(const G& g, hipStream_t st) {
+  return serl_gemm(g.a, g.b, g.c, g.bias, g.nb, g.M, g.N, g.K, g.seglen ? g.seglen : g.K, g.a_zs, g.a_ss, g.a_ms, g.a_ks,
+                   g.b_zs, g.b_ss, g.b_ks, g.b_ns, g.c_zs, g.c_ms, g.bias_zs, g.nsplit, g.c_split, g.relu, g.acc, g.a_kc,
+                   g.b_nc, st);
+}
+int colsum(const float* x0, float* out0, int ng, int rpg, int N, int ldx, long long out_gs, hipStream_t st,
+           const float* w = nullptr, const float* mul = nullptr, const float* x1 = nullptr, float* out1 = nullptr,
+           const float* x2 = nullptr, const float* mul2 = nullptr, float* out2 = nullptr) {
+  return serl_colsum(x0, w, mul, out0, x1, out1, x2, mul2, out2, ng, rpg, N, ldx, out_gs, st);
+}
+
+int ksplit(int K) {   // split-K factor for the skinny (M = batch) GEMMs so that >= ~256 blocks are in flight
+  if (K < 1024) return 1;
+  int n = 8;
+  while (n > 1 && (K + n - 1) / n < 256) n /= 2;
+  const int klen = ((K + n - 1) / n + 15) / 16 * 16;
+  return (K + klen - 1) / klen;
+}
+
+void bias_corrections(int step, float* bc1, float* bc2) {   // 1 - b^t in float32 like optax
+  *bc1 = 1.0f - powf(ADAM_B1, (float)step);
+  *bc2 = 1.0f - powf(ADAM_B2, (float)step);
+}
+
+void split2(const uint32_t k[2], uint32_t c0[2], uint32_t c1[2]) {   // c0, c1 = jax.random.split(k)
+  uint32_t a0, a1, b0, b1;
+  threefry_split_child(k[0], k[1], 2, 0, a0, a1);
+  threefry_split_child(k[0], k[1], 2, 1, b0, b1);
+  c0[0] = a0; c0[1] = a1; c1[0] = b0; c1[1] = b1;
+}
+
+bool split_conv_stack(const Cfg& c) {   // the conv stack runs on S-format tensors (include/serl_hip.h)
+  if (serl_get_matmul_precision() != 1) return false;
+  for (int li = 0; li < c.nl; ++li) {
+    const ConvL& L = c.L[li];
+    if (L.F % 8 || (li == 0 ? L.K * L.C > 32 : L.C % 8 != 0) || L.S > 2) return false;
+  }
+  return true;
+}
+
+void conv_cost(int kind, int in_u8, int n, int B, const ConvL& L, double* flops, double* bytes) {
+  // algorithmic (flops, HBM bytes) of one grouped conv launch: every tensor read or written once
+  const double x = (double)n * B * L.IH * L.IW * L.C * (in_u8 ? 1 : 4);
+  const double y = (double)n * B * L.OH * L.OW * L.F * 4;
+  const double w = (double)n * L.K * L.K * L.C * L.F * 4;
+  *flops = 2.0 * n * B * L.OH * L.OW * L.F * L.K * L.K * L.C;
+  if (kind == 0) *bytes = x + w + y + n * L.F * 4.0;
+  else if (kind == 1) *bytes = y + w + x / 2 + x;
+  else *bytes = x + y + w + n * L.F * 4.0;
+}
+
+struct Timed {   // RAII-free bracket: begin() before the launch, end() after, both on the launch stream
+  serl_learner* h; hipStream_t st; int idx = -1;
+  int begin(int kind, int in_u8, int n, int B, const ConvL& L) {
+    if (!h->timing) return SERL_OK;
+    TimeRec r{kind, in_u8, n, B, L.IH, L.C, L.F, 0, 0, nullptr, nullptr};
+    conv_cost(kind, in_u8, n, B, L, &r.flops, &r.bytes);
+    DRV_HIP(hipEventCreate(&r.a));
+    DRV_HIP(hipEventCreate(&r.b));
+    DRV_HIP(hipEventRecord(r.a, st));
+    h->trecs.push_back(r);
+    idx = (int)h->trecs.size() - 1;
+    return SERL_OK;
+  }
+  int end() {
+    if (idx >= 0) DRV_HIP(hipEventRecord(h->trecs[idx].b, st));
+    return SERL_OK;
+  }
+};
+
+// `to` waits for everything enqueued on `from` so far (no-op when they are the same stream)
+int link(hipStream_t from, hipStream_t to, hipEvent_t ev) {
+  if (from == to) return SERL_OK;
+  DRV_HIP(hipEventRecord(ev, from));
+  DRV_HIP(hipStreamWaitEvent(to, ev, 0));
+  return SERL_OK;
+}
+
+int phase(serl_learner* h, const char* name, hipStream_t st) {
+  if (!h->phases) return SERL_OK;
+  PhaseRec r{name, nullptr};
+  DRV_HIP(hipEventCreate(&r.ev));
+  DRV_HIP(hipEventRecord(r.ev, st));
+  h->precs.push_back(r);
+  return SERL_OK;
+}
+
+// ================================================================= encoder (TwoD4PGEncoder + SpatialLearnedEmbeddings)
+struct Pass { char tag; Store store; const EncOff* eo; const unsigned char* imgs[MAX_CAM]; };
+
+size_t rmask_floats(int B, const ConvL& L) { return ((size_t)B * L.OH * L.OW * L.F / 8 + 3) / 4; }
+
+int encoder_fwd(serl_learner* h, const Pass* passes, int npass, int B, Workspace& ws, hipStream_t st, char mask_tag,
+                bool prep) {
+  const Cfg& c = h->cfg;
+  const int nl = c.nl, ncam = c.ncam;
+  const bool split = split_conv_stack(c);
+  struct Grp { const Pass* p; int ci; };
+  std::vector<Grp> groups;
+  for (int i = 0; i < npass; ++i)
+    for (int ci = 0; ci < ncam; ++ci) groups.push_back(Grp{&passes[i], ci});
+  const ConvL& last = c.L[nl - 1];
+  for (size_t g0 = 0; g0 < groups.size(); g0 += MAXG_) {
+    const int n = (int)std::min<size_t>(MAXG_, groups.size() - g0);
+    const Grp* ch = &groups[g0];
+    const void* xs[MAXG_];
+    void* wf_all[MAX_CONV][MAXG_];
+    for (int i = 0; i < n; ++i) xs[i] = ch[i].p->imgs[ch[i].ci];
+    if (split) {
+      const float* jw[32]; void* jwf[32]; void* jwd[32]; int ju8[32], jk[32], jc[32], jf[32];
+      int nj = 0;
+      auto flush = [&]() -> int {
+        if (nj && prep) DRV(serl_convs_prep_weights_multi(nj, jw, jwf, jwd, ju8, jk, jk, jc, jf, st));
+        nj = 0;
+        return SERL_OK;
+      };
+      for (int li = 0; li < nl; ++li) {
+        const ConvL& L = c.L[li];
+        const long long nwf = serl_convs_weight_bytes(li == 0, L.K, L.K, L.C, L.F) / 4;
+        for (int i = 0; i < n; ++i) {
+          WSF(ws, st, wf, nwf, "wf%d_%c_%d", li, ch[i].p->tag, ch[i].ci);
+          float* wd = nullptr;
+          if (li > 0) {
+            WSF(ws, st, wd_, (size_t)L.K * L.K * L.C * L.F, "wd%d_%c_%d", li, ch[i].p->tag, ch[i].ci);
+            wd = wd_;
+          }
+          wf_all[li][i] = wf;
+          jw[nj] = ch[i].p->store.at(ch[i].p->eo->ck[ch[i].ci][li]); jwf[nj] = wf; jwd[nj] = wd;
+          ju8[nj] = li == 0; jk[nj] = L.K; jc[nj] = L.C; jf[nj] = L.F;
+          if (++nj == 32) DRV(flush());
+        }
+      }
+      DRV(flush());   // every (layer, group) in one launch, ahead of the dependent chain of conv kernels
+    }
+    for (int li = 0; li < nl; ++li) {
+      const ConvL& L = c.L[li];
+      const float* wsp[MAXG_]; const float* bsp[MAXG_]; void* ys[MAXG_]; void* rm[MAXG_];
+      bool any_mask = false;
+      for (int i = 0; i < n; ++i) {
+        const Pass* p = ch[i].p;
+        wsp[i] = p->store.at(p->eo->ck[ch[i].ci][li]);
+        bsp[i] = p->store.at(p->eo->cb[ch[i].ci][li]);
+        WSF(ws, st, y, (size_t)B * L.OH * L.OW * L.F, "act%d_%c_%d", li, p->tag, ch[i].ci);
+        ys[i] = y;
+        rm[i] = nullptr;
+        if (split && mask_tag && li < nl - 1 && p->tag == mask_tag) {
+          WSF(ws, st, r, rmask_floats(B, L), "rmask%d_%c_%d", li, p->tag, ch[i].ci);
+          rm[i] = r;
+          any_mask = true;
+        }
+      }
+      Timed t{h, st};
+      DRV(t.begin(0, li == 0, n, B, L));
+      if (split)
+        DRV(serl_convs_fwd(n, xs, (const void* const*)wf_all[li], bsp, ys, li == 0, B, L.IH, L.IW, L.C, L.K, L.K, L.S, L.F,
+                           1, any_mask ? rm : nullptr, st));
+      else
+        DRV(serl_conv2d_fwd(n, xs, wsp, bsp, (float* const*)ys, li == 0, B, L.IH, L.IW, L.C, L.K, L.K, L.S, L.F, 1, st));
+      DRV(t.end());
+      for (int i = 0; i < n; ++i) xs[i] = ys[i];
+    }
+    const void* feats[MAXG_]; const float* kers[MAXG_]; float* outs[MAXG_];
+    for (int i = 0; i < n; ++i) {
+      const Pass* p = ch[i].p;
+      feats[i] = xs[i];
+      kers[i] = p->store.at(p->eo->sle[ch[i].ci]);
+      WSF(ws, st, enc, (size_t)B * c.enc_dim, "enc_%c", p->tag);
+      outs[i] = enc + (size_t)ch[i].ci * last.F * SLE_FEATURES;
+    }
+    DRV(serl_sle_fwd(n, feats, kers, outs, c.enc_dim, B, last.OH * last.OW, last.F, SLE_FEATURES, split, st));
+  }
+  return SERL_OK;
+}
+
+int encoder_bwd(serl_learner* h, char tag, const Store& store, const EncOff& eo, const Store& grads,
+                const unsigned char* const* imgs, int B, Workspace& ws, hipStream_t st, GradSide* gside, bool use_masks) {
+  const Cfg& c = h->cfg;
+  const int nl = c.nl, ncam = c.ncam;
+  const ConvL& last = c.L[nl - 1];
+  const bool split = split_conv_stack(c);
+  WSF(ws, st, denc, (size_t)B * c.enc_dim, "denc_%c", tag);
+  const float* douts[MAX_CAM]; const float* kers[MAX_CAM]; const void* feats[MAX_CAM]; void* dfeat[MAX_CAM]; float* dker[MAX_CAM];
+  for (int ci = 0; ci < ncam; ++ci) {
+    douts[ci] = denc + (size_t)ci * last.F * SLE_FEATURES;
+    kers[ci] = store.at(eo.sle[ci]);
+    WSF(ws, st, f, (size_t)B * last.OH * last.OW * last.F, "act%d_%c_%d", nl - 1, tag, ci);
+    feats[ci] = f;
+    WSF(ws, st, df, (size_t)B * last.OH * last.OW * last.F, "dact%d_%d", nl - 1, ci);
+    dfeat[ci] = df;
+    dker[ci] = grads.at(eo.sle[ci]);
+  }
+  const int HW = last.OH * last.OW;
+  if (!gside) {
+    DRV(serl_sle_bwd(ncam, douts, c.enc_dim, kers, feats, dfeat, dker, B, HW, last.F, SLE_FEATURES, split, st));
+  } else {
+    hipStream_t sw;
+    DRV(gside->fork(&sw));
+    DRV(serl_sle_bwd(ncam, douts, c.enc_dim, kers, feats, nullptr, dker, B, HW, last.F, SLE_FEATURES, split, sw));
+    DRV(serl_sle_bwd(ncam, douts, c.enc_dim, kers, feats, dfeat, nullptr, B, HW, last.F, SLE_FEATURES, split, st));
+  }
+  long long slab_bytes = 0;
+  for (int li = 0; li < nl; ++li) {
+    const ConvL& L = c.L[li];
+    const long long b = serl_conv2d_wgrad_workspace_bytes(ncam, B, L.IH, L.IW, L.C, L.K, L.K, L.S, L.F);
+    SERL_CHECK_ARG(b >= 0, "learner: bad conv geometry in layer %d", li);
+    slab_bytes = std::max(slab_bytes, b);
+  }
+  WSF(ws, st, slab, (size_t)slab_bytes / 4, "wgrad_slab");
+  for (int li = nl - 1; li >= 0; --li) {
+    const ConvL& L = c.L[li];
+    const void* dz[MAX_CAM]; const void* xs[MAX_CAM]; float* dw[MAX_CAM]; float* db[MAX_CAM];
+    for (int ci = 0; ci < ncam; ++ci) {
+      WSF(ws, st, d, (size_t)B * L.OH * L.OW * L.F, "dact%d_%d", li, ci);
+      dz[ci] = d;
+      if (li == 0) {
+        xs[ci] = imgs[ci];
+      } else {
+        const ConvL& P = c.L[li - 1];
+        WSF(ws, st, x, (size_t)B * P.OH * P.OW * P.F, "act%d_%c_%d", li - 1, tag, ci);
+        xs[ci] = x;
+      }
+      dw[ci] = grads.at(eo.ck[ci][li]);
+      db[ci] = grads.at(eo.cb[ci][li]);
+    }
+    hipStream_t sw = st;
+    if (gside) DRV(gside->fork(&sw));   // dz of this layer is ready on the main stream here
+    {
+      Timed t{h, sw};
+      DRV(t.begin(2, li == 0, ncam, B, L));
+      if (split)
+        DRV(serl_convs_wgrad(ncam, xs, dz, dw, db, slab, slab_bytes, li == 0, B, L.IH, L.IW, L.C, L.K, L.K, L.S, L.F, sw));
+      else
+        DRV(serl_conv2d_wgrad(ncam, xs, (const float* const*)dz, dw, db, slab, slab_bytes, li == 0, B, L.IH, L.IW, L.C,
+                              L.K, L.K, L.S, L.F, sw));
+      DRV(t.end());
+    }
+    if (li > 0) {
+      const ConvL& P = c.L[li - 1];
+      void* dx[MAX_CAM];
+      for (int ci = 0; ci < ncam; ++ci) {
+        WSF(ws, st, d, (size_t)B * P.OH * P.OW * P.F, "dact%d_%d", li - 1, ci);
+        dx[ci] = d;
+      }
+      Timed t{h, st};
+      DRV(t.begin(1, 0, ncam, B, L));
+      if (split) {
+        const void* wds[MAX_CAM]; const void* rm[MAX_CAM];
+        for (int ci = 0; ci < ncam; ++ci) {
+          WSF(ws, st, wd, (size_t)L.K * L.K * L.C * L.F, "wd%d_%c_%d", li, tag, ci);
+          wds[ci] = wd;
+          if (use_masks) {
+            WSF(ws, st, r, rmask_floats(B, P), "rmask%d_%c_%d", li - 1, tag, ci);
+            rm[ci] = r;
+          }
+        }
+        DRV(serl_convs_dgrad(ncam, dz, wds, use_masks ? rm : xs, dx, B, L.IH, L.IW, L.C, L.K, L.K, L.S, L.F,
+                             use_masks ? 1 : 0, st));
+      } else {
+        const float* wk[MAX_CAM];
+        for (int ci = 0; ci < ncam; ++ci) wk[ci] = store.at(eo.ck[ci][li]);
+        DRV(serl_conv2d_dgrad(ncam, (const float* const*)dz, wk, (const float* const*)xs, (float* const*)dx, B, L.IH,
+                              L.IW, L.C, L.K, L.K, L.S, L.F, st));
+      }
+      DRV(t.end());
+    }
+  }
+  return SERL_OK;
+}
+
+// ================================================================= trunk (PixelMultiplexer Dense/LN/tanh branches)
+int trunk_fwd(serl_learner* h, char tag, const Store& s, const EncOff& eo, const float* state_ptr, float* z, int ldz, int B,
+              Workspace& ws, hipStream_t st, bool save) {
+  const Cfg& c = h->cfg;
+  const int K = c.enc_dim, ns = ksplit(K), Ld = c.latent_dim, Sd = c.state_dim;
+  WSF(ws, st, slab, (size_t)ns * B * TRUNK_DIM, "slab0_%c", tag);
+  WSF(ws, st, enc, (size_t)B * K, "enc_%c", tag);
+  G g; g.a = enc; g.b = s.at(eo.d0k); g.c = slab; g.M = B; g.N = TRUNK_DIM; g.K = K; g.a_ms = K; g.a_ks = 1;
+  g.b_ks = TRUNK_DIM; g.b_ns = 1; g.c_ms = TRUNK_DIM; g.nsplit = ns; g.c_split = (long long)B * TRUNK_DIM;
+  DRV(gemm(g, st));
+  float *xh0 = nullptr, *rs0 = nullptr, *xh1 = nullptr, *rs1 = nullptr;
+  if (save) {
+    WSF(ws, st, a, (size_t)B * TRUNK_DIM, "xhat0_%c", tag); xh0 = a;
+    WSF(ws, st, b, (size_t)B, "rstd0_%c", tag); rs0 = b;
+    WSF(ws, st, a1, (size_t)B * Ld, "xhat1_%c", tag); xh1 = a1;
+    WSF(ws, st, b1, (size_t)B, "rstd1_%c", tag); rs1 = b1;
+  }
+  return serl_trunk_ln_fwd(slab, ns, (long long)B * TRUNK_DIM, TRUNK_DIM, s.at(eo.d0b), s.at(eo.l0s), s.at(eo.l0b), z, xh0,
+                           rs0, state_ptr, Sd, Sd, s.at(eo.d1k), Ld, s.at(eo.d1b), s.at(eo.l1s), s.at(eo.l1b),
+                           z + TRUNK_DIM, xh1, rs1, ldz, B, ACT_TANH, st);
+}
+
+int trunk_bwd(serl_learner* h, char tag, const Store& s, const EncOff& eo, const Store& gr, const float* state_ptr,
+              const float* z, int ldz, const float* dz, int lddz, int B, Workspace& ws, hipStream_t st, bool need_denc,
+              GradSide* gside, int dz_nslab, long long dz_ss) {
+  const Cfg& c = h->cfg;
+  const int K = c.enc_dim, Ld = c.latent_dim, Sd = c.state_dim;
+  WSF(ws, st, dpre0, (size_t)B * TRUNK_DIM, "dpre0");
+  WSF(ws, st, g0, (size_t)B * TRUNK_DIM, "g0");
+  WSF(ws, st, xh0, (size_t)B * TRUNK_DIM, "xhat0_%c", tag);
+  WSF(ws, st, rs0, (size_t)B, "rstd0_%c", tag);
+  WSF(ws, st, dpre1, (size_t)B * Ld, "dpre1");
+  WSF(ws, st, g1, (size_t)B * Ld, "g1");
+  WSF(ws, st, xh1, (size_t)B * Ld, "xhat1_%c", tag);
+  WSF(ws, st, rs1, (size_t)B, "rstd1_%c", tag);
+  const float* dy[2] = {dz, dz + TRUNK_DIM}; int lddy[2] = {lddz, lddz};
+  const float* y[2] = {z, z + TRUNK_DIM}; int ldy[2] = {ldz, ldz};
+  const float* xh[2] = {xh0, xh1}; const float* rs[2] = {rs0, rs1};
+  const float* gam[2] = {s.at(eo.l0s), s.at(eo.l1s)};
+  float* dzo[2] = {dpre0, dpre1}; float* go[2] = {g0, g1}; int N[2] = {TRUNK_DIM, Ld};
+  DRV(serl_ln_act_bwd_seg(2, dy, lddy, dz_nslab, dz_ss, y, ldy, xh, rs, gam, dzo, go, B, N, ACT_TANH, st));
+  hipStream_t stw = st;
+  if (gside) DRV(gside->fork(&stw));
+  DRV(colsum(g0, gr.at(eo.l0b), 1, B, TRUNK_DIM, TRUNK_DIM, 0, stw, nullptr, nullptr, dpre0, gr.at(eo.d0b), g0, xh0,
+             gr.at(eo.l0s)));
+  WSF(ws, st, enc, (size_t)B * K, "enc_%c", tag);
+  {
+    G g; g.a = enc; g.b = dpre0; g.c = gr.at(eo.d0k); g.M = K; g.N = TRUNK_DIM; g.K = B; g.a_ms = 1; g.a_ks = K;
+    g.b_ks = TRUNK_DIM; g.b_ns = 1; g.c_ms = TRUNK_DIM; g.a_kc = 0;
+    DRV(gemm(g, stw));
+  }
+  if (need_denc) {
+    WSF(ws, st, denc, (size_t)B * K, "denc_%c", tag);
+    G g; g.a = dpre0; g.b = s.at(eo.d0k); g.c = denc; g.M = B; g.N = K; g.K = TRUNK_DIM; g.a_ms = TRUNK_DIM; g.a_ks = 1;
+    g.b_ks = 1; g.b_ns = TRUNK_DIM; g.c_ms = K; g.b_nc = 0;
+    DRV(gemm(g, st));
+  }
+  DRV(colsum(g1, gr.at(eo.l1b), 1, B, Ld, Ld, 0, stw, nullptr, nullptr, dpre1, gr.at(eo.d1b), g1, xh1, gr.at(eo.l1s)));
+  G g; g.a = state_ptr; g.b = dpre1; g.c = gr.at(eo.d1k); g.M = Sd; g.N = Ld; g.K = B; g.a_ms = 1; g.a_ks = Sd;
+  g.b_ks = Ld; g.b_ns = 1; g.c_ms = Ld; g.a_kc = 0;
+  return gemm(g, stw);
+}
+
+// ================================================================= critic ensemble (Ensemble(StateActionValue(MLP)))
+// members m0, m0 + mstride, ... (E of them) on a shared input (B, ld_inp); *q_out = (E, B)
+int ensemble_fwd(serl_learner* h, char tag, const Store& s, const CriticOff& co, int m0, int mstride, int E,
+                 const float* inp, int ld_inp, int B, Workspace& ws, hipStream_t st, bool save, float** q_out) {
+  const Cfg& c = h->cfg;
+  int din = c.latent + c.A;
+  const int nl = c.nh, hl = c.hid[nl - 1];
+  const float* a_ptr = inp; long long a_zs = 0, a_ms = ld_inp;
+  WSF(ws, st, q, (size_t)E * B, "q_%c", tag);
+  const float* head_w = s.at(co.hk) + (long long)m0 * hl;
+  const float* head_b = s.at(co.hb) + m0;
+  for (int i = 0; i < nl; ++i) {
+    const int hd = c.hid[i];
+    const float* W = s.at(co.w[i]) + (long long)m0 * din * hd;
+    const float* bias = s.at(co.b[i]) + (long long)m0 * hd;
+    WSF(ws, st, hbuf, (size_t)E * B * hd, "h%d_%c", i, tag);
+    if (c.ln) {
+      WSF(ws, st, pbuf, (size_t)E * B * hd, "epre%d_%c", i, tag);
+      G g; g.a = a_ptr; g.b = W; g.c = pbuf; g.nb = E; g.M = B; g.N = hd; g.K = din; g.a_zs = a_zs; g.a_ms = a_ms; g.a_ks = 1;
+      g.b_zs = (long long)mstride * din * hd; g.b_ks = hd; g.b_ns = 1; g.c_zs = (long long)B * hd; g.c_ms = hd;
+      DRV(gemm(g, st));
+      float *xh = nullptr, *rs = nullptr;
+      if (save) {
+        WSF(ws, st, a, (size_t)E * B * hd, "exh%d_%c", i, tag); xh = a;
+        WSF(ws, st, b, (size_t)E * B, "ers%d_%c", i, tag); rs = b;
+      }
+      const float* gam = s.at(co.lns[i]) + (long long)m0 * hd;
+      const float* bet = s.at(co.lnb[i]) + (long long)m0 * hd;
+      if (i == nl - 1)   // the last hidden layer's launch also applies the Dense(1) Q head
+        DRV(serl_ln_act_head_fwd(pbuf, 1, 0, hd, bias, gam, bet, (long long)mstride * hd, hbuf, hd, xh, rs, E * B, hd, B, 1,
+                                 ACT_RELU, head_w, (long long)mstride * hl, head_b, mstride, q, st));
+      else
+        DRV(serl_ln_act_fwd(pbuf, 1, 0, hd, bias, gam, bet, (long long)mstride * hd, hbuf, hd, xh, rs, E * B, hd, B, 1,
+                            ACT_RELU, st));
+    } else {
+      G g; g.a = a_ptr; g.b = W; g.c = hbuf; g.bias = bias; g.nb = E; g.M = B; g.N = hd; g.K = din; g.a_zs = a_zs;
+      g.a_ms = a_ms; g.a_ks = 1; g.b_zs = (long long)mstride * din * hd; g.b_ks = hd; g.b_ns = 1; g.c_zs = (long long)B * hd;
+      g.c_ms = hd; g.bias_zs = (long long)mstride * hd; g.relu = 1;
+      DRV(gemm(g, st));
+    }
+    a_ptr = hbuf; a_zs = (long long)B * hd; a_ms = hd; din = hd;
+  }
+  if (!c.ln) DRV(serl_rowdot(a_ptr, head_w, (long long)mstride * hl, head_b, mstride, q, E * B, din, B, st));
+  *q_out = q;
+  return SERL_OK;
+}
+
+// Backward of the full ensemble from dq (E, B).  Parameter gradients into `grads` when given.  want_dinp: 0 none,
+// 1 summed (B, latent+action), 2 split-K slabs (the consumer sums them on read).  Result in dinp / nslab / slab_stride.
+int ensemble_bwd(serl_learner* h, char tag, const Store& s, const CriticOff& co, const Store* grads, const float* dq,
+                 const float* inp, int ld_inp, int B, Workspace& ws, hipStream_t st, GradSide* gside, int want_dinp,
+                 float** dinp_out, int* nslab_out, long long* ss_out) {
+  const Cfg& c = h->cfg;
+  const int E = c.E, ln = c.ln, nl = c.nh;
+  int dims[MAX_HID + 1];
+  dims[0] = c.latent + c.A;
+  for (int i = 0; i < nl; ++i) dims[i + 1] = c.hid[i];
+  const int hl = dims[nl];
+  hipStream_t stw = st;
+  if (grads) {
+    if (gside) DRV(gside->fork(&stw));
+    WSF(ws, st, hlast, (size_t)E * B * hl, "h%d_%c", nl - 1, tag);
+    DRV(colsum(hlast, grads->at(co.hk), E, B, hl, hl, hl, stw, dq));
+    DRV(colsum(dq, grads->at(co.hb), E, B, 1, 1, 1, stw));
+  }
+  const float* dy = nullptr;
+  for (int i = nl - 1; i >= 0; --i) {
+    const int hd = dims[i + 1], hp = dims[i];
+    WSF(ws, st, hbuf, (size_t)E * B * hd, "h%d_%c", i, tag);
+    WSF(ws, st, dz, (size_t)E * B * hd, "edz%d", i);
+    float *g = nullptr, *xh = nullptr, *rs = nullptr; const float* gam = nullptr;
+    if (ln) {
+      WSF(ws, st, g_, (size_t)E * B * hd, "eg%d", i); g = g_;
+      WSF(ws, st, x_, (size_t)E * B * hd, "exh%d_%c", i, tag); xh = x_;
+      WSF(ws, st, r_, (size_t)E * B, "ers%d_%c", i, tag); rs = r_;
+      gam = s.at(co.lns[i]);
+    }
+    if (i == nl - 1)
+      DRV(serl_ln_act_bwd(nullptr, 0, dq, s.at(co.hk), hd, hbuf, hd, xh, rs, gam, hd, dz, g, E * B, hd, B, ln, ACT_RELU, st));
+    else
+      DRV(serl_ln_act_bwd(dy, hd, nullptr, nullptr, 0, hbuf, hd, xh, rs, gam, hd, dz, g, E * B, hd, B, ln, ACT_RELU, st));
+    const float* W = s.at(co.w[i]);
+    if (grads) {
+      float* gb = grads->at(co.b[i]);
+      if (gside) DRV(gside->fork(&stw));   // after this layer's ln_act_bwd
+      if (ln)
+        DRV(colsum(g, grads->at(co.lnb[i]), E, B, hd, hd, hd, stw, nullptr, nullptr, dz, gb, g, xh, grads->at(co.lns[i])));
+      else
+        DRV(colsum(dz, gb, E, B, hd, hd, hd, stw));
+      const float* a_ptr; long long a_zs, a_ks;
+      if (i == 0) { a_ptr = inp; a_zs = 0; a_ks = ld_inp; }
+      else { WSF(ws, st, hprev, (size_t)E * B * hp, "h%d_%c", i - 1, tag); a_ptr = hprev; a_zs = (long long)B * hp; a_ks = hp; }
+      G gg; gg.a = a_ptr; gg.b = dz; gg.c = grads->at(co.w[i]); gg.nb = E; gg.M = hp; gg.N = hd; gg.K = B; gg.a_zs = a_zs;
+      gg.a_ms = 1; gg.a_ks = a_ks; gg.b_zs = (long long)B * hd; gg.b_ks = hd; gg.b_ns = 1; gg.c_zs = (long long)hp * hd;
+      gg.c_ms = hd; gg.a_kc = 0;
+      DRV(gemm(gg, stw));
+    }
+    if (i > 0) {
+      WSF(ws, st, dh, (size_t)E * B * hp, "edh%d", i - 1);
+      G gg; gg.a = dz; gg.b = W; gg.c = dh; gg.nb = E; gg.M = B; gg.N = hp; gg.K = hd; gg.a_zs = (long long)B * hd; gg.a_ms = hd;
+      gg.a_ks = 1; gg.b_zs = (long long)hp * hd; gg.b_ks = 1; gg.b_ns = hd; gg.c_zs = (long long)B * hp; gg.c_ms = hp; gg.b_nc = 0;
+      DRV(gemm(gg, st));
+      dy = dh;
+    } else if (want_dinp == 0) {
+      return SERL_OK;
+    } else {
+      WSF(ws, st, dinp, (size_t)B * hp, "dinp");
+      const int ns = ksplit(E * hd);   // few (M, N) tiles and a long K = (member, feature) loop: split it
+      G gg; gg.a = dz; gg.b = W; gg.M = B; gg.N = hp; gg.K = E * hd; gg.seglen = hd; gg.a_ss = (long long)B * hd; gg.a_ms = hd;
+      gg.a_ks = 1; gg.b_ss = (long long)hp * hd; gg.b_ks = 1; gg.b_ns = hd; gg.c_ms = hp; gg.b_nc = 0;
+      if (ns > 1) {
+        WSF(ws, st, slab, (size_t)ns * B * hp, "dinp_slab");
+        gg.c = slab; gg.nsplit = ns; gg.c_split = (long long)B * hp;
+        DRV(gemm(gg, st));
+        if (want_dinp == 2) { *dinp_out = slab; *nslab_out = ns; *ss_out = (long long)B * hp; return SERL_OK; }
+        DRV(serl_ln_act_fwd(slab, ns, (long long)B * hp, hp, nullptr, nullptr, nullptr, 0, dinp, hp, nullptr, nullptr, B, hp,
+                            B, 0, ACT_NONE, st));
+      } else {
+        gg.c = dinp;
+        DRV(gemm(gg, st));
+      }
+      *dinp_out = dinp; *nslab_out = 1; *ss_out = 0;
+    }
+  }
+  return SERL_OK;
+}
+
+// ================================================================= policy head (TanhNormal(MLP))
+int policy_fwd(serl_learner* h, char tag, const Store& s, const ActorOff& ao, const float* z, int ldz, int B, Workspace& ws,
+               hipStream_t st, const uint32_t* key, int row_offset, int total_rows, float* act, int ld_act,
+               bool deterministic, bool save, bool want_logp, float* logp_out, float** logp_ret) {
+  const Cfg& c = h->cfg;
+  const int A = c.A;
+  const float* a_ptr = z; long long a_ms = ldz; int din = c.latent;
+  for (int i = 0; i < c.nh; ++i) {
+    const int hd = c.hid[i];
+    WSF(ws, st, hbuf, (size_t)B * hd, "ph%d_%c", i, tag);
+    G g; g.a = a_ptr; g.b = s.at(ao.w[i]); g.c = hbuf; g.bias = s.at(ao.b[i]); g.M = B; g.N = hd; g.K = din; g.a_ms = a_ms;
+    g.a_ks = 1; g.b_ks = hd; g.b_ns = 1; g.c_ms = hd; g.relu = 1;
+    DRV(gemm(g, st));
+    a_ptr = hbuf; a_ms = hd; din = hd;
+  }
+  WSF(ws, st, ms, (size_t)B * 2 * A, "ms_%c", tag);
+  {
+    G g; g.a = a_ptr; g.b = s.at(ao.mk); g.c = ms; g.bias = s.at(ao.mb); g.nb = 2; g.M = B; g.N = A; g.K = din; g.a_zs = 0;
+    g.a_ms = a_ms; g.a_ks = 1; g.b_zs = ao.lk - ao.mk; g.b_ks = A; g.b_ns = 1; g.c_zs = A; g.c_ms = 2 * A;
+    g.bias_zs = ao.lb - ao.mb;
+    DRV(gemm(g, st));
+  }
+  float* logp = nullptr;
+  if (want_logp) {
+    if (logp_out) logp = logp_out;
+    else { WSF(ws, st, l, (size_t)B, "logp_%c", tag); logp = l; }
+  }
+  float* eps = nullptr;
+  if (save) { WSF(ws, st, e, (size_t)B * A, "eps_%c", tag); eps = e; }
+  DRV(serl_tanh_gaussian_fwd(ms, ms + A, 2 * A, act, ld_act, nullptr, eps, logp, B, A, key ? key[0] : 0, key ? key[1] : 0,
+                             row_offset, total_rows, deterministic, st));
+  if (logp_ret) *logp_ret = logp;
+  return SERL_OK;
+}
+
+// backward from ws["dms"] (B, 2A) = [dmean | dlogstd]; *dz_out = (B, latent) when need_dz
+int policy_bwd(serl_learner* h, char tag, const Store& s, const ActorOff& ao, const Store& gr, const float* z, int ldz,
+               int B, Workspace& ws, hipStream_t st, bool need_dz, float** dz_out) {
+  const Cfg& c = h->cfg;
+  const int A = c.A, nl = c.nh;
+  int dims[MAX_HID + 1];
+  dims[0] = c.latent;
+  for (int i = 0; i < nl; ++i) dims[i + 1] = c.hid[i];
+  const int hl = dims[nl];
+  WSF(ws, st, dms, (size_t)B * 2 * A, "dms");
+  WSF(ws, st, hlast, (size_t)B * hl, "ph%d_%c", nl - 1, tag);
+  {
+    G g; g.a = hlast; g.b = dms; g.c = gr.at(ao.mk); g.nb = 2; g.M = hl; g.N = A; g.K = B; g.a_zs = 0; g.a_ms = 1; g.a_ks = hl;
+    g.b_zs = A; g.b_ks = 2 * A; g.b_ns = 1; g.c_zs = ao.lk - ao.mk; g.c_ms = A; g.a_kc = 0;
+    DRV(gemm(g, st));
+  }
+  DRV(colsum(dms, gr.at(ao.mb), 1, B, A, 2 * A, 0, st));
+  DRV(colsum(dms + A, gr.at(ao.lb), 1, B, A, 2 * A, 0, st));
+  WSF(ws, st, dh0, (size_t)B * hl, "pdh%d", nl - 1);
+  {
+    G g; g.a = dms; g.b = s.at(ao.mk); g.c = dh0; g.M = B; g.N = hl; g.K = 2 * A; g.seglen = A; g.a_ss = A; g.a_ms = 2 * A;
+    g.a_ks = 1; g.b_ss = ao.lk - ao.mk; g.b_ks = 1; g.b_ns = A; g.c_ms = hl; g.b_nc = 0;
+    DRV(gemm(g, st));
+  }
+  float* dh = dh0;
+  for (int i = nl - 1; i >= 0; --i) {
+    const int hd = dims[i + 1], hp = dims[i];
+    WSF(ws, st, hbuf, (size_t)B * hd, "ph%d_%c", i, tag);
+    WSF(ws, st, dz, (size_t)B * hd, "pdz%d", i);
+    DRV(serl_ln_act_bwd(dh, hd, nullptr, nullptr, 0, hbuf, hd, nullptr, nullptr, nullptr, 0, dz, nullptr, B, hd, B, 0,
+                        ACT_RELU, st));
+    DRV(colsum(dz, gr.at(ao.b[i]), 1, B, hd, hd, 0, st));
+    const float* a_ptr; long long a_ks;
+    if (i == 0) { a_ptr = z; a_ks = ldz; }
+    else { WSF(ws, st, hprev, (size_t)B * hp, "ph%d_%c", i - 1, tag); a_ptr = hprev; a_ks = hp; }
+    {
+      G g; g.a = a_ptr; g.b = dz; g.c = gr.at(ao.w[i]); g.M = hp; g.N = hd; g.K = B; g.a_ms = 1; g.a_ks = a_ks; g.b_ks = hd;
+      g.b_ns = 1; g.c_ms = hd; g.a_kc = 0;
+      DRV(gemm(g, st));
+    }
+    if (i > 0 || need_dz) {
+      float* nd;
+      if (i > 0) { WSF(ws, st, x, (size_t)B * hp, "pdh%d", i - 1); nd = x; }
+      else { WSF(ws, st, x, (size_t)B * hp, "pdzlat"); nd = x; }
+      G g; g.a = dz; g.b = s.at(ao.w[i]); g.c = nd; g.M = B; g.N = hp; g.K = hd; g.a_ms = hd; g.a_ks = 1; g.b_ks = 1;
+      g.b_ns = hd; g.c_ms = hp; g.b_nc = 0;
+      DRV(gemm(g, st));
+      dh = nd;
+    }
+  }
+  if (dz_out) *dz_out = need_dz ? dh : nullptr;
+  return SERL_OK;
+}
+
+// ================================================================= feature stage of one or more passes
+struct Feats {   // device inputs of the call, rows [0, n)
+  const float* obs = nullptr; const float* next_obs = nullptr;         // state-based: (n, obs_dim)
+  const float* state = nullptr; const float* next_state = nullptr;     // pixel-based: (n, state_dim)
+  unsigned char* aug[2][MAX_CAM] = {};                                 // [obs|next][sorted cam] (n, H, W, 3*S) uint8
+};
+struct FPass { char tag; Store store; const EncOff* eo; int which; float* z; hipStream_t trunk_stream; };   // which: 0 obs, 1 next
+
+int features(serl_learner* h, const FPass* passes, int npass, const Feats& f, int lo, int B, Workspace& ws, hipStream_t st,
+             char save_tag, hipEvent_t fork, bool prep) {
+  const Cfg& c = h->cfg;
+  if (!c.pixel) {
+    if (fork)
+      for (int i = 0; i < npass; ++i) DRV(link(st, passes[i].trunk_stream, fork));
+    for (int i = 0; i < npass; ++i) {
+      const float* src = passes[i].which ? f.next_obs : f.obs;
+      DRV(serl_copy2d(passes[i].z, c.ldz, src + (size_t)lo * c.obs_dim, c.obs_dim, B, c.obs_dim, passes[i].trunk_stream));
+    }
+    return SERL_OK;
+  }
+  const size_t img_bytes = (size_t)c.H * c.W * 3 * c.stack;
+  Pass ep[4];
+  for (int i = 0; i < npass; ++i) {
+    ep[i].tag = passes[i].tag; ep[i].store = passes[i].store; ep[i].eo = passes[i].eo;
+    for (int ci = 0; ci < c.ncam; ++ci) ep[i].imgs[ci] = f.aug[passes[i].which][ci] + lo * img_bytes;
+  }
+  DRV(encoder_fwd(h, ep, npass, B, ws, st, save_tag, prep));
+  if (fork)     // the trunks of the passes are independent: side streams wait for the encoders
+    for (int i = 0; i < npass; ++i) DRV(link(st, passes[i].trunk_stream, fork));
+  for (int i = 0; i < npass; ++i) {
+    const float* state = (passes[i].which ? f.next_state : f.state) + (size_t)lo * c.state_dim;
+    DRV(trunk_fwd(h, passes[i].tag, passes[i].store, *passes[i].eo, state, passes[i].z, c.ldz, B, ws, passes[i].trunk_stream,
+                  passes[i].tag == save_tag));
+  }
+  return SERL_OK;
+}
+
+int features_bwd(serl_learner* h, char tag, const Store& store, const EncOff& eo, const Store& grads, const Feats& f, int lo,
+                 int B, Workspace& ws, hipStream_t st, const float* dz, int lddz, bool need_encoder, GradSide* gside,
+                 int dz_nslab, long long dz_ss) {
+  const Cfg& c = h->cfg;
+  if (!c.pixel) return SERL_OK;   // no trainable feature stage for state inputs
+  WSF(ws, st, z, (size_t)B * c.ldz, "z%c", tag);
+  DRV(trunk_bwd(h, tag, store, eo, grads, f.state + (size_t)lo * c.state_dim, z, c.ldz, dz, lddz, B, ws, st, need_encoder,
+                gside, dz_nslab, dz_ss));
+  if (need_encoder) {
+    const size_t img_bytes = (size_t)c.H * c.W * 3 * c.stack;
+    const unsigned char* imgs[MAX_CAM];
+    for (int ci = 0; ci < c.ncam; ++ci) imgs[ci] = f.aug[0][ci] + lo * img_bytes;
+    DRV(encoder_bwd(h, tag, store, eo, grads, imgs, B, ws, st, gside, true));
+  }
+  return SERL_OK;
+}
+
+// REDQ subsample (serl/networks/ensemble.py:25-37) -> first member / member stride when the picked members form an
+// arithmetic sequence (always for 2 of E), else a gathered copy of the members in a scratch store
+int target_members(serl_learner* h, const uint32_t key[2], const Store& target, Workspace& ws, hipStream_t st, int* m0,
+                   int* mstride, int* emin, Store* tstore) {
+  const Cfg& c = h->cfg;
+  *tstore = target;
+  if (c.num_min_qs <= 0) { *m0 = 0; *mstride = 1; *emin = c.E; return SERL_OK; }
+  int idx[64];
+  SERL_CHECK_ARG(c.num_min_qs <= 64, "learner: num_min_qs > 64");
+  DRV(serl_prng_choice(key[0], key[1], c.E, c.num_min_qs, idx));
+  const int m = c.num_min_qs;
+  *emin = m;
+  if (m == 1) { *m0 = idx[0]; *mstride = 1; return SERL_OK; }
+  const int d = idx[1] - idx[0];
+  bool arith = true;
+  for (int i = 0; i + 1 < m; ++i) arith = arith && (idx[i + 1] - idx[i] == d);
+  if (arith) { *m0 = idx[0]; *mstride = d; return SERL_OK; }
+  // general num_min_qs > 2: copy the chosen members of the head leaves into a scratch store (rare path)
+  const CriticOff& co = h->co;
+  WSF(ws, st, scratch, (size_t)co.size, "tgt_scratch");
+  int dims[MAX_HID + 1];
+  dims[0] = c.latent + c.A;
+  for (int i = 0; i < c.nh; ++i) dims[i + 1] = c.hid[i];
+  auto gather = [&](long long off, long long per) -> int {
+    for (int j = 0; j < m; ++j)
+      DRV(serl_copy2d(scratch + off + j * per, (int)per, target.base + off + idx[j] * per, (int)per, 1, (int)per, st));
+    return SERL_OK;
+  };
+  for (int i = 0; i < c.nh; ++i) {
+    DRV(gather(co.w[i], (long long)dims[i] * dims[i + 1]));
+    DRV(gather(co.b[i], dims[i + 1]));
+    if (c.ln) { DRV(gather(co.lns[i], dims[i + 1])); DRV(gather(co.lnb[i], dims[i + 1])); }
+  }
+  DRV(gather(co.hk, dims[c.nh]));
+  DRV(gather(co.hb, 1));
+  tstore->base = scratch;
+  *m0 = 0; *mstride = 1;
+  return SERL_OK;
+}
+
+}  // namespace
+
+// ================================================================= C ABI
+extern "C" int serl_learner_create(const serl_learner_config* pc, const long long* critic_offsets, int n_critic,
+                                   const long long* actor_offsets, int n_actor, serl_learner** out) {
+  SERL_CHECK_ARG(pc && critic_offsets && actor_offsets && out, "learner_create: null pointer");
+  SERL_CHECK_ARG(pc->num_hidden >= 1 && pc->num_hidden <= MAX_HID, "learner_create: 1..%d hidden layers", MAX_HID);
+  SERL_CHECK_ARG(pc->num_qs >= 1 && pc->action_dim >= 1, "learner_create: bad ensemble / action size");
+  SERL_CHECK_ARG(!pc->pixel || (pc->num_cameras >= 1 && pc->num_cameras <= MAX_CAM && pc->num_conv >= 1 &&
+                                pc->num_conv <= MAX_CONV),
+                 "learner_create: 1..%d cameras, 1..%d conv layers", MAX_CAM, MAX_CONV);
+  serl_learner* h = new serl_learner();
+  Cfg& c = h->cfg;
+  memset(&c, 0, sizeof(c));
+  c.A = pc->action_dim; c.nh = pc->num_hidden; c.E = pc->num_qs; c.num_min_qs = pc->num_min_qs;
+  for (int i = 0; i < c.nh; ++i) c.hid[i] = pc->hidden_dims[i];
+  c.ln = pc->critic_layer_norm; c.backup_entropy = pc->backup_entropy; c.has_temp = pc->has_temperature;
+  c.pixel = pc->pixel; c.obs_dim = pc->obs_dim; c.ncam = pc->num_cameras; c.H = pc->height; c.W = pc->width;
+  c.stack = pc->stack; c.state_dim = pc->state_dim; c.latent_dim = pc->latent_dim; c.nl = pc->num_conv;
+  c.discount = pc->discount; c.tau = pc->tau; c.target_entropy = pc->target_entropy;
+  c.actor_lr = pc->actor_lr; c.critic_lr = pc->critic_lr; c.temp_lr = pc->temp_lr;
+  if (c.pixel) {
+    int hh = c.H, ww = c.W, cc = 3 * c.stack;
+    for (int li = 0; li < c.nl; ++li) {
+      const int f = pc->cnn_features[li], k = pc->cnn_filters[li], s = pc->cnn_strides[li];
+      if (k < 1 || s < 1 || f < 1 || hh < k || ww < k) {
+        delete h;
+        SERL_CHECK_ARG(false, "learner_create: conv layer %d does not fit its input", li);
+      }
+      ConvL& L = c.L[li];
+      L.IH = hh; L.IW = ww; L.C = cc; L.K = k; L.S = s; L.F = f; L.OH = (hh - k) / s + 1; L.OW = (ww - k) / s + 1;
+      hh = L.OH; ww = L.OW; cc = f;
+    }
+    for (int ci = 0; ci < c.ncam; ++ci) c.aug_rank[ci] = pc->aug_rank[ci];
+    c.enc_dim = c.ncam * c.L[c.nl - 1].F * SLE_FEATURES;
+    c.latent = TRUNK_DIM + c.latent_dim;
+  } else {
+    c.latent = c.obs_dim;
+  }
+  c.ldz = c.latent + c.A;
+  // parameter leaf offsets, in the order serl_amd/networks/spec.py lays the stores out
+  auto enc = [&](const long long* o, int n, int* cur, EncOff* e) -> bool {
+    const int need = c.ncam * c.nl * 2 + c.ncam + 8;
+    if (*cur + need > n) return false;
+    for (int ci = 0; ci < c.ncam; ++ci)
+      for (int li = 0; li < c.nl; ++li) { e->ck[ci][li] = o[(*cur)++]; e->cb[ci][li] = o[(*cur)++]; }
+    for (int ci = 0; ci < c.ncam; ++ci) e->sle[ci] = o[(*cur)++];
+    e->d0k = o[(*cur)++]; e->d0b = o[(*cur)++]; e->l0s = o[(*cur)++]; e->l0b = o[(*cur)++];
+    e->d1k = o[(*cur)++]; e->d1b = o[(*cur)++]; e->l1s = o[(*cur)++]; e->l1b = o[(*cur)++];
+    return true;
+  };
+  bool ok = true;
+  int cur = 0;
+  memset(&h->co, 0, sizeof(h->co));
+  memset(&h->ao, 0, sizeof(h->ao));
+  if (c.pixel) ok = ok && enc(critic_offsets, n_critic, &cur, &h->co.e);
+  const int per = c.ln ? 4 : 2;
+  ok = ok && cur + c.nh * per + 3 == n_critic;
+  if (ok) {
+    for (int i = 0; i < c.nh; ++i) {
+      h->co.w[i] = critic_offsets[cur++]; h->co.b[i] = critic_offsets[cur++];
+      if (c.ln) { h->co.lns[i] = critic_offsets[cur++]; h->co.lnb[i] = critic_offsets[cur++]; }
+    }
+    h->co.hk = critic_offsets[cur++]; h->co.hb = critic_offsets[cur++];
+    h->co.size = critic_offsets[cur++];   // last entry: total size of the store in floats
+  }
+  cur = 0;
+  if (ok && c.pixel) ok = enc(actor_offsets, n_actor, &cur, &h->ao.e);
+  ok = ok && cur + c.nh * 2 + 5 == n_actor;
+  if (ok) {
+    for (int i = 0; i < c.nh; ++i) { h->ao.w[i] = actor_offsets[cur++]; h->ao.b[i] = actor_offsets[cur++]; }
+    h->ao.mk = actor_offsets[cur++]; h->ao.lk = actor_offsets[cur++]; h->ao.mb = actor_offsets[cur++];
+    h->ao.lb = actor_offsets[cur++];
+    h->ao.size = actor_offsets[cur++];
+  }
+  if (!ok) {
+    delete h;
+    SERL_CHECK_ARG(false, "learner_create: offset tables do not match the network description (%d critic, %d actor entries)",
+                   n_critic, n_actor);
+  }
+  hipError_t e = hipGetDevice(&h->device);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->s1, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->astream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->gside.own, hipStreamNonBlocking);
+  hipEvent_t* evs[] = {&h->fork_ev, &h->join1, &h->astart, &h->agate, &h->aobs};
+  for (hipEvent_t* ev : evs)
+    if (e == hipSuccess) e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
+  if (e != hipSuccess) {
+    serl_set_error("learner_create: %s", hipGetErrorString(e));
+    delete h;
+    return SERL_ERR_HIP;
+  }
+  *out = h;
+  return SERL_OK;
+}
+
+extern "C" int serl_learner_destroy(serl_learner* h) {
+  if (!h) return SERL_OK;
+  (void)hipDeviceSynchronize();
+  for (auto& kv : h->ws_update) kv.second.release();
+  h->ws_act.release();
+  if (h->s1) (void)hipStreamDestroy(h->s1);
+  if (h->astream) (void)hipStreamDestroy(h->astream);
+  if (h->gside.own) (void)hipStreamDestroy(h->gside.own);
+  for (hipEvent_t e : h->gside.ev) (void)hipEventDestroy(e);
+  for (hipEvent_t e : h->adone) (void)hipEventDestroy(e);
+  for (hipEvent_t e : {h->fork_ev, h->join1, h->astart, h->agate, h->aobs})
+    if (e) (void)hipEventDestroy(e);
+  for (auto& r : h->trecs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  for (auto& r : h->precs) (void)hipEventDestroy(r.ev);
+  delete h;
+  return SERL_OK;
+}
+
+// One whole update(batch, utd_ratio): see the file header.  Everything is enqueued; nothing waits for the GPU.
+extern "C" int serl_learner_update(serl_learner* h, const serl_agent_buffers* ag, const serl_update_batch* bt, int utd,
+                                   const unsigned* rng_in, unsigned* rng_out, float* info_out, void* stream,
+                                   serl_allreduce_fn allreduce, void* allreduce_ctx, int rank, int world) {
+  SERL_CHECK_ARG(h && ag && bt && rng_in && rng_out && info_out, "learner_update: null pointer");
+  SERL_CHECK_ARG(utd >= 1 && bt->n >= utd && bt->n % utd == 0, "learner_update: batch of %d rows is not divisible by utd_ratio %d", bt->n, utd);
+  SERL_CHECK_ARG(world >= 1 && rank >= 0 && rank < world && (world == 1 || allreduce), "learner_update: bad rank / world / allreduce");
+  const Cfg& c = h->cfg;
+  const CriticOff& co = h->co;
+  const ActorOff& ao = h->ao;
+  const int n = bt->n, B = n / utd, A = c.A, ldz = c.ldz, E = c.E, Bg = B * world;
+  // Pixel learners spread a call over four streams (file header).  State-based learners are a string of ~20 small,
+  // latency-bound launches per critic step: there a cross-stream dependency (hipEventRecord + hipStreamWaitEvent, ~10-20 us
+  // of host time each) costs more than the overlap returns, so everything runs on the caller's stream.
+  const bool multi = c.pixel != 0;
+  hipStream_t st = (hipStream_t)stream, s1 = multi ? h->s1 : st, sta = multi ? h->astream : st;
+  Workspace& ws = h->ws_update[B];
+  const Store actor{ag->actor}, critic{ag->critic}, target{ag->target};
+  const Store cgr{ag->critic_grads}, agr{ag->actor_grads};
+  float* log_temp = ag->temp;
+
+  // ---- rng chain of the call.  aug_mode 1 (DrQLearner.update, drq_learner.py:174-177):
+  // rng, key = split(rng) twice (rng is child 0).  aug_mode 2 (PixelDDPGLearner.update, pixel_ddpg_learner.py:167-180):
+  // key, rng = split(rng) twice, and the update itself runs on the rng the augmentation did NOT advance.
+  uint32_t rng[2] = {rng_in[0], rng_in[1]}, key_obs[2] = {0, 0}, key_next[2] = {0, 0};
+  if (c.pixel) {
+    uint32_t a[2], b[2];
+    if (bt->aug_mode == 2) {
+      split2(rng, key_obs, a);
+      split2(a, key_next, b);
+    } else {
+      split2(rng, a, key_obs);
+      split2(a, b, key_next);
+      rng[0] = b[0]; rng[1] = b[1];
+    }
+  }
+  std::vector<uint32_t> step_keys((size_t)utd * 4);
+  for (int i = 0; i < utd; ++i) {
+    uint32_t k[2], r[2];
+    split2(rng, k, r); step_keys[4 * i] = k[0]; step_keys[4 * i + 1] = k[1];         // next-action noise
+    split2(r, k, rng); step_keys[4 * i + 2] = k[0]; step_keys[4 * i + 3] = k[1];     // subsample_ensemble
+    split2(rng, k, r);                                                               // target dropout key (consumed, unused)
+    split2(r, k, rng);                                                               // critic dropout key
+  }
+  uint32_t key_pi[2], tmp[2], r2[2];
+  split2(rng, key_pi, r2);       // actor step (sac_learner.py:121-122): policy sample key
+  split2(r2, tmp, rng);          // ... and its critic dropout key
+  rng_out[0] = rng[0]; rng_out[1] = rng[1];
+
+  // ---- inputs
+  Feats f;
+  f.obs = bt->obs; f.next_obs = bt->next_obs; f.state = bt->state; f.next_state = bt->next_state;
+  SERL_CHECK_ARG(bt->actions && bt->rewards && bt->masks, "learner_update: actions / rewards / masks missing");
+  if (!c.pixel) SERL_CHECK_ARG(f.obs && f.next_obs, "learner_update: observations missing");
+  float* info = info_out;   // 8 floats of the caller: the data-parallel hook all-reduces its first 4
+  if (c.pixel) {
+    // fused frame-stack gather + _unpack + random shift of all B*U rows, one kernel per (side, camera); crop offsets
+    // keyed by the GLOBAL row index so that rank shards reproduce the single-process stream
+    SERL_CHECK_ARG(f.state && f.next_state, "learner_update: state leaves missing");
+    const int S = c.stack, pad = 4;   // batched_random_crop(..., padding=4), serl/utils/augmentations.py:44
+    const size_t img = (size_t)c.H * c.W * 3 * S;
+    for (int side = 0; side < 2; ++side) {
+      // keys in the caller's pixel_keys order: key, rng = split(rng) per camera (drq_learner.py:131-137)
+      uint32_t cam_key[MAX_CAM][2], kk[2] = {side ? key_next[0] : key_obs[0], side ? key_next[1] : key_obs[1]};
+      for (int p = 0; p < c.ncam; ++p) {
+        uint32_t k[2], r[2];
+        split2(kk, k, r);
+        cam_key[p][0] = k[0]; cam_key[p][1] = k[1];
+        kk[0] = r[0]; kk[1] = r[1];
+      }
+      for (int ci = 0; ci < c.ncam; ++ci) {
+        const uint32_t* key = cam_key[c.aug_rank[ci]];
+        WSB(ws, st, int, off, (size_t)n * 2 * 4, "off_%d_%d", side, ci);
+        if (world == 1) {
+          DRV(serl_crop_offsets(key[0], key[1], n, 0, n, pad, off, st));
+        } else {
+          for (int i = 0; i < utd; ++i)
+            DRV(serl_crop_offsets(key[0], key[1], B, i * B * world + rank * B, n * world, pad, off + 2 * i * B, st));
+        }
+        WSB(ws, st, unsigned char, dst, (size_t)n * img, "aug_%d_%d", side, ci);
+        f.aug[side][ci] = dst;
+        const serl_pixel_source& src = bt->pixels[ci];
+        if (src.kind == 0) {          // device frame store + window indices
+          SERL_CHECK_ARG(src.frames && src.indx, "learner_update: frame store source without frames / indices");
+          DRV(serl_gather_crop_frames(src.frames, src.capacity, src.indx, S + 1, side, off, dst, n, c.H, c.W, S, pad, st));
+        } else if (src.kind == 1) {   // packed (n,H,W,3,S+1)
+          SERL_CHECK_ARG(src.obs, "learner_update: packed source missing");
+          DRV(serl_gather_crop_packed(src.obs, S + 1, side, off, dst, n, c.H, c.W, S, pad, st));
+        } else {                      // unpacked: obs (n,H,W,3,S) and next_obs (n,H,W,3,S)
+          const unsigned char* p = side ? src.next_obs : src.obs;
+          SERL_CHECK_ARG(p, "learner_update: unpacked source missing");
+          DRV(serl_gather_crop_packed(p, S, 0, off, dst, n, c.H, c.W, S, pad, st));
+        }
+      }
+    }
+  }
+
+  WSF(ws, st, zA, (size_t)B * ldz, "zA");
+  WSF(ws, st, zC, (size_t)B * ldz, "zC");
+  WSF(ws, st, zP, (size_t)B * ldz, "zC_pi");                    // critic input of the actor step
+  WSF(ws, st, zT_all, (size_t)utd * B * ldz, "zT_all");         // per-step inputs of the target ensemble
+  WSF(ws, st, nlogp_all, (size_t)utd * B, "nlogp_all");
+  WSF(ws, st, dq, (size_t)E * B, "dq");
+  WSF(ws, st, target_q, (size_t)B, "target_q");
+  WSF(ws, st, logpA, (size_t)B, "logp_A");
+  while ((int)h->adone.size() < utd) {
+    hipEvent_t e;
+    DRV_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    h->adone.push_back(e);
+  }
+
+  // ---- the actor's no-grad pass over next_obs runs one step ahead on its own stream (constant parameters in the loop)
+  DRV(link(st, sta, h->astart));
+  auto enqueue_actor = [&](int j) -> int {
+    FPass p{'A', actor, &ao.e, 1, zA, sta};
+    DRV(features(h, &p, 1, f, j * B, B, ws, sta, 0, nullptr, j == 0));   // S-format weight copies made once (j == 0)
+    DRV(policy_fwd(h, 'A', actor, ao, zA, ldz, B, ws, sta, &step_keys[4 * j], rank * B, Bg,
+                   zT_all + ((size_t)j * B * ldz + c.latent), ldz, false, false, c.backup_entropy != 0,
+                   nlogp_all + (size_t)j * B, nullptr));
+    if (sta != st) DRV_HIP(hipEventRecord(h->adone[j], sta));
+    return SERL_OK;
+  };
+  auto enqueue_actor_obs = [&]() -> int {   // behind the last pass: the actor's own pass over obs for the actor step
+    FPass p{'A', actor, &ao.e, 0, zA, sta};
+    DRV(features(h, &p, 1, f, (utd - 1) * B, B, ws, sta, 'A', nullptr, false));
+    DRV(policy_fwd(h, 'A', actor, ao, zA, ldz, B, ws, sta, key_pi, rank * B, Bg, zP + c.latent, ldz, false, true, true, logpA,
+                   nullptr));
+    if (sta != st) DRV_HIP(hipEventRecord(h->aobs, sta));
+    return SERL_OK;
+  };
+  DRV(enqueue_actor(0));
+
+  int critic_step = ag->critic_step;
+  for (int i = 0; i < utd; ++i) {
+    const int lo = i * B;
+    DRV(phase(h, "step", st));
+    // ---- critic step (sac_learner.py:160-219)
+    int m0, mstride, emin;
+    Store tstore;
+    DRV(target_members(h, &step_keys[4 * i + 2], target, ws, st, &m0, &mstride, &emin, &tstore));
+    float* zT = zT_all + (size_t)i * B * ldz;
+    {
+      // target chain on the main stream, critic chain on a side stream, next action from the actor stream
+      FPass ps[2] = {{'T', target, &co.e, 1, zT, st}, {'C', critic, &co.e, 0, zC, s1}};
+      DRV(features(h, ps, 2, f, lo, B, ws, st, 'C', h->fork_ev, true));
+    }
+    DRV(phase(h, "features_fwd", st));
+    // start pass i+1 when the main stream leaves its (HBM-bound) encoder forward
+    DRV(link(st, sta, h->agate));
+    if (i + 1 < utd) DRV(enqueue_actor(i + 1));
+    else DRV(enqueue_actor_obs());
+    if (sta != st) DRV_HIP(hipStreamWaitEvent(st, h->adone[i], 0));
+    float *next_q, *q;
+    DRV(ensemble_fwd(h, 'T', tstore, co, m0, mstride, emin, zT, ldz, B, ws, st, false, &next_q));
+    DRV(serl_copy2d(zC + c.latent, ldz, bt->actions + (size_t)lo * A, A, B, A, s1));
+    DRV(ensemble_fwd(h, 'C', critic, co, 0, 1, E, zC, ldz, B, ws, s1, true, &q));
+    DRV(link(s1, st, h->join1));
+    DRV(serl_td_loss(next_q, emin, bt->rewards + lo, bt->masks + lo, c.backup_entropy ? nlogp_all + (size_t)i * B : nullptr,
+                     log_temp, c.discount, q, E, B, 1.0f / ((float)E * Bg), target_q, dq, info, st));
+    DRV(phase(h, "heads_fwd", st));
+    h->gside.begin(st, multi);
+    // pixel learners: the trunk backward sums the split-K slabs of the input gradient on read; state-based:
+    // observations are not trainable, the critic step needs no input gradient at all
+    float* dinp = nullptr; int nslab = 1; long long ss = 0;
+    DRV(ensemble_bwd(h, 'C', critic, co, &cgr, dq, zC, ldz, B, ws, st, &h->gside, c.pixel ? 2 : 0, &dinp, &nslab, &ss));
+    DRV(phase(h, "ensemble_bwd", st));
+    DRV(features_bwd(h, 'C', critic, co.e, cgr, f, lo, B, ws, st, dinp, ldz, true, &h->gside, nslab, ss));
+    DRV(h->gside.join());
+    DRV(phase(h, "features_bwd", st));
+    if (world > 1) DRV(allreduce(allreduce_ctx, 0));   // data parallel: one all-reduce(sum) of the flat gradient per step
+    ++critic_step;
+    float bc1, bc2;
+    bias_corrections(critic_step, &bc1, &bc2);
+    DRV(serl_adam_polyak(critic.base, ag->critic_mu, ag->critic_nu, cgr.base, target.base, co.size, c.critic_lr, ADAM_B1,
+                         ADAM_B2, ADAM_EPS, bc1, bc2, c.tau, 1.0f, st));
+  }
+
+  // ---- actor step on the last minibatch (sac_learner.py:120-144, 235)
+  DRV(phase(h, "actor", st));
+  const int lo = (utd - 1) * B;
+  // the actor's own pass over obs ran ahead; only the critic pass with the post-UTD critic parameters is left here
+  if (sta != st) DRV_HIP(hipStreamWaitEvent(st, h->aobs, 0));
+  {
+    FPass p{'C', critic, &co.e, 0, zP, st};
+    DRV(features(h, &p, 1, f, lo, B, ws, st, 0, nullptr, true));
+  }
+  float* q;
+  DRV(ensemble_fwd(h, 'C', critic, co, 0, 1, E, zP, ldz, B, ws, st, true, &q));
+  DRV(serl_actor_loss(q, E, B, logpA, log_temp, info + 2, st));
+  DRV(serl_fill(dq, -1.0f / ((float)E * Bg), (long long)E * B, st));
+  float* dinp = nullptr; int nslab = 1; long long ss = 0;
+  DRV(ensemble_bwd(h, 'C', critic, co, nullptr, dq, zP, ldz, B, ws, st, nullptr, 1, &dinp, &nslab, &ss));
+  WSF(ws, st, dms, (size_t)B * 2 * A, "dms");
+  WSF(ws, st, msA, (size_t)B * 2 * A, "ms_A");
+  WSF(ws, st, epsA, (size_t)B * A, "eps_A");
+  DRV(serl_tanh_gaussian_bwd(zP + c.latent, ldz, epsA, msA + A, 2 * A, dinp + c.latent, ldz, log_temp, 1.0f / Bg, dms,
+                             dms + A, 2 * A, B, A, st));
+  float* dzlat = nullptr;
+  DRV(policy_bwd(h, 'A', actor, ao, agr, zA, ldz, B, ws, st, c.pixel != 0, &dzlat));
+  DRV(features_bwd(h, 'A', actor, ao.e, agr, f, lo, B, ws, st, dzlat, c.latent, false, nullptr, 1, 0));
+  if (world > 1) {
+    DRV(allreduce(allreduce_ctx, 1));   // actor gradient
+    DRV(allreduce(allreduce_ctx, 2));   // loss / q / logp sums -> global before the temperature step
+  }
+  float bc1, bc2;
+  bias_corrections(ag->actor_step + 1, &bc1, &bc2);
+  DRV(serl_adam_polyak(actor.base, ag->actor_mu, ag->actor_nu, agr.base, nullptr, ao.size, c.actor_lr, ADAM_B1, ADAM_B2,
+                       ADAM_EPS, bc1, bc2, 0.0f, 1.0f, st));
+  // ---- temperature (sac_learner.py:146-158, 236)
+  if (c.has_temp) {
+    bias_corrections(ag->temp_step + 1, &bc1, &bc2);
+    DRV(serl_temperature_update(log_temp, info + 3, 1.0f / Bg, c.target_entropy, c.temp_lr, ADAM_B1, ADAM_B2, ADAM_EPS, bc1,
+                                bc2, info + 4, st));
+  }
+  DRV(phase(h, "end", st));
+  return SERL_OK;
+}
+
+// One policy evaluation on a single observation (serl/agents/agent.py:12-37): encoder + trunk + TanhNormal head with the
+// given actor parameters.  act_out (A floats) / eps_out (A floats, may be NULL) are device pointers.
+extern "C" int serl_learner_act(serl_learner* h, const float* actor_params, const unsigned char* const* images,
+                                const float* state_or_obs, const unsigned* key, int deterministic, float* act_out,
+                                float* eps_out, void* stream) {
+  SERL_CHECK_ARG(h && actor_params && state_or_obs && act_out, "learner_act: null pointer");
+  std::lock_guard<std::mutex> lock(h->act_mu);
+  const Cfg& c = h->cfg;
+  hipStream_t st = (hipStream_t)stream;
+  Workspace& ws = h->ws_act;
+  const Store actor{(float*)actor_params};
+  WSF(ws, st, z, (size_t)c.ldz, "zA");
+  if (c.pixel) {
+    SERL_CHECK_ARG(images, "learner_act: images missing");
+    Pass p; p.tag = 'A'; p.store = actor; p.eo = &h->ao.e;
+    for (int ci = 0; ci < c.ncam; ++ci) p.imgs[ci] = images[ci];
+    DRV(encoder_fwd(h, &p, 1, 1, ws, st, 0, true));
+    DRV(trunk_fwd(h, 'A', actor, h->ao.e, state_or_obs, z, c.ldz, 1, ws, st, false));
+  } else {
+    DRV(serl_copy2d(z, c.ldz, state_or_obs, c.obs_dim, 1, c.obs_dim, st));
+  }
+  const bool save = eps_out != nullptr;
+  DRV(policy_fwd(h, 'A', actor, h->ao, z, c.ldz, 1, ws, st, key, 0, 1, act_out, c.A, deterministic != 0, save, false, nullptr,
+                 nullptr));
+  if (save) {
+    WSF(ws, st, eps, (size_t)c.A, "eps_A");
+    DRV_HIP(hipMemcpyAsync(eps_out, eps, c.A * sizeof(float), hipMemcpyDeviceToDevice, st));
+  }
+  return SERL_OK;
+}
+
+// Copy `nbytes` of a named workspace buffer of the last update at minibatch size B into dst (device), on `stream`:
+// tests read the augmented images ("aug_<side>_<cam>", side 0 obs / 1 next_obs, cam in sorted order) this way.
+extern "C" int serl_learner_read_buffer(serl_learner* h, int B, const char* name, void* dst, long long nbytes, void* stream) {
+  SERL_CHECK_ARG(h && name && dst && nbytes >= 0, "learner_read_buffer: bad args");
+  auto w = h->ws_update.find(B);
+  SERL_CHECK_ARG(w != h->ws_update.end(), "learner_read_buffer: no update with minibatch size %d has run", B);
+  auto it = w->second.m.find(name);
+  SERL_CHECK_ARG(it != w->second.m.end(), "learner_read_buffer: no buffer named %s", name);
+  SERL_CHECK_ARG((size_t)nbytes <= it->second.bytes, "learner_read_buffer: %s holds %zu bytes", name, it->second.bytes);
+  DRV_HIP(hipMemcpyAsync(dst, it->second.p, (size_t)nbytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return SERL_OK;
+}
+
+extern "C" long long serl_learner_workspace_bytes(serl_learner* h) {
+  if (!h) return 0;
+  long long t = 0;
+  for (auto& kv : h->ws_update)
+    for (auto& b : kv.second.m) t += (long long)b.second.bytes;
+  for (auto& b : h->ws_act.m) t += (long long)b.second.bytes;
+  return t;
+}
+
+// ---- instrumentation for bench.py: HIP events around every conv launch (on the launch stream) / between phases
+extern "C" int serl_learner_set_timing(serl_learner* h, int conv_events, int phase_events) {
+  SERL_CHECK_ARG(h, "learner_set_timing: null handle");
+  h->timing = conv_events != 0;
+  h->phases = phase_events != 0;
+  return SERL_OK;
+}
+extern "C" int serl_learner_timing_count(serl_learner* h) { return h ? (int)h->trecs.size() : 0; }
+// record i -> desc[7] = {kind (0 fwd, 1 dgrad, 2 wgrad), in_u8, groups, B, IH, C, F}, val[3] = {ms, flops, bytes};
+// call after a device synchronise.
+extern "C" int serl_learner_timing_get(serl_learner* h, int i, int* desc, double* val) {
+  SERL_CHECK_ARG(h && desc && val && i >= 0 && i < (int)h->trecs.size(), "learner_timing_get: bad index");
+  const TimeRec& r = h->trecs[i];
+  float ms = 0;
+  DRV_HIP(hipEventElapsedTime(&ms, r.a, r.b));
+  desc[0] = r.kind; desc[1] = r.in_u8; desc[2] = r.groups; desc[3] = r.B; desc[4] = r.IH; desc[5] = r.C; desc[6] = r.F;
+  val[0] = ms; val[1] = r.flops; val[2] = r.bytes;
+  return SERL_OK;
+}
+extern "C" int serl_learner_phase_count(serl_learner* h) { return h ? (int)h->precs.size() : 0; }
+// mark i: name (static string) and the milliseconds from mark i to mark i+1 (0 for the last one)
+extern "C" int serl_learner_phase_get(serl_learner* h, int i, const char** name, double* ms_to_next) {
+  SERL_CHECK_ARG(h && name && ms_to_next && i >= 0 && i < (int)h->precs.size(), "learner_phase_get: bad index");
+  *name = h->precs[i].name;
+  float ms = 0;
+  if (i + 1 < (int)h->precs.size()) DRV_HIP(hipEventElapsedTime(&ms, h->precs[i].ev, h->precs[i + 1].ev));
+  *ms_to_next = ms;
+  return SERL_OK;
+}
+extern "C" int serl_learner_timing_reset(serl_learner* h) {
+  SERL_CHECK_ARG(h, "learner_timing_reset: null handle");
+  for (auto& r : h->trecs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  for (auto& r : h->precs) (void)hipEventDestroy(r.ev);
+  h->trecs.clear();
+  h->precs.clear();
+  return SERL_OK;
+}

@@ -14,46 +14,6 @@ def current_stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
-PHASES = None   # tools/phases.py: list of (name, event) recorded on the current stream at the marks below
-
-
-def phase(name):
-    if PHASES is not None:
-        import torch
-        ev = torch.cuda.Event(enable_timing=True)
-        ev.record()
-        PHASES.append((name, ev))
-
-
-class KernelTimer:
-    """Optional HIP-event bracket around the conv launches (bench.py's live roofline measurement).
-    Events are recorded on the stream handle the kernel is launched on (rec), which for the parameter-gradient
-    kernels is a side stream, not torch's current one."""
-
-    def __init__(self):
-        self.records = {}
-
-    def bracket(self, key, cost):
-        import torch
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        self.records.setdefault(key, []).append((a, b, cost))
-        return a, b
-
-    @staticmethod
-    def rec(ev, stream):
-        import torch
-        ev.record(torch.cuda.ExternalStream(stream) if stream else torch.cuda.default_stream())
-
-    def summary(self):
-        """key -> (launches, mean ms, algorithmic flops per launch, algorithmic HBM bytes per launch);
-        call after a device synchronize."""
-        out = {}
-        for key, recs in self.records.items():
-            ms = [a.elapsed_time(b) for a, b, _ in recs]
-            out[key] = (len(ms), sum(ms) / len(ms), recs[0][2][0], recs[0][2][1])
-        return out
-
-
 def conv_cost(kind, in_u8, n, B, IH, IW, C, KH, KW, stride, F):
     """Algorithmic (flops, HBM bytes) of one grouped conv launch: every tensor is read or
     written once; activations and gradients are 4 bytes per element in either format, uint8 pixels 1 byte."""
@@ -71,33 +31,16 @@ def conv_cost(kind, in_u8, n, B, IH, IW, C, KH, KW, stride, F):
     return flops, float(byts)
 
 
-TIMER = None   # set to a KernelTimer to enable
-
-
 def conv2d_fwd(xs, ws, bs, ys, in_u8, B, IH, IW, C, KH, KW, stride, F, relu, stream):
     n = len(xs)
     px, kx = ptr_table(xs); pw, kw = ptr_table(ws); pb, kb = ptr_table(bs); py, ky = ptr_table(ys)
-    ev = None
-    if TIMER is not None:
-        ev = TIMER.bracket(("conv2d_fwd", bool(in_u8), n, B, IH, C, F),
-                           conv_cost("fwd", bool(in_u8), n, B, IH, IW, C, KH, KW, stride, F))
-        TIMER.rec(ev[0], stream)
     call("serl_conv2d_fwd", n, px, pw, pb, py, int(in_u8), B, IH, IW, C, KH, KW, stride, F, int(relu), stream)
-    if ev is not None:
-        TIMER.rec(ev[1], stream)
 
 
 def conv2d_dgrad(dzs, ws, xacts, dxs, B, IH, IW, C, KH, KW, stride, F, stream):
     n = len(dzs)
     pz, kz = ptr_table(dzs); pw, kw = ptr_table(ws); pa, ka = ptr_table(xacts); pd, kd = ptr_table(dxs)
-    ev = None
-    if TIMER is not None:
-        ev = TIMER.bracket(("conv2d_dgrad", False, n, B, IH, C, F),
-                           conv_cost("dgrad", False, n, B, IH, IW, C, KH, KW, stride, F))
-        TIMER.rec(ev[0], stream)
     call("serl_conv2d_dgrad", n, pz, pw, pa, pd, B, IH, IW, C, KH, KW, stride, F, stream)
-    if ev is not None:
-        TIMER.rec(ev[1], stream)
 
 
 def conv2d_wgrad_workspace_bytes(ngroups, B, IH, IW, C, KH, KW, stride, F) -> int:
@@ -149,42 +92,21 @@ def convs_prep_weights_multi(jobs, stream):
 def convs_fwd(xs, wfs, bs, ys, in_u8, B, IH, IW, C, KH, KW, stride, F, relu, stream, rmasks=None):
     n = len(xs)
     px, kx = ptr_table(xs); pw, kw = ptr_table(wfs); pb, kb = ptr_table(bs); py, ky = ptr_table(ys)
-    ev = None
-    if TIMER is not None:
-        ev = TIMER.bracket(("convs_fwd", bool(in_u8), n, B, IH, C, F),
-                           conv_cost("fwd", bool(in_u8), n, B, IH, IW, C, KH, KW, stride, F))
-        TIMER.rec(ev[0], stream)
     pm, km = ptr_table(rmasks) if rmasks is not None else (None, None)
     call("serl_convs_fwd", n, px, pw, pb, py, int(in_u8), B, IH, IW, C, KH, KW, stride, F, int(relu), pm, stream)
-    if ev is not None:
-        TIMER.rec(ev[1], stream)
 
 
 def convs_dgrad(dzs, wds, xacts, dxs, B, IH, IW, C, KH, KW, stride, F, stream, xact_bits=False):
     n = len(dzs)
     pz, kz = ptr_table(dzs); pw, kw = ptr_table(wds); pa, ka = ptr_table(xacts); pd, kd = ptr_table(dxs)
-    ev = None
-    if TIMER is not None:
-        ev = TIMER.bracket(("convs_dgrad", False, n, B, IH, C, F),
-                           conv_cost("dgrad", False, n, B, IH, IW, C, KH, KW, stride, F))
-        TIMER.rec(ev[0], stream)
     call("serl_convs_dgrad", n, pz, pw, pa, pd, B, IH, IW, C, KH, KW, stride, F, int(xact_bits), stream)
-    if ev is not None:
-        TIMER.rec(ev[1], stream)
 
 
 def convs_wgrad(xs, dzs, dws, dbs, workspace, workspace_bytes, in_u8, B, IH, IW, C, KH, KW, stride, F, stream):
     n = len(xs)
     px, kx = ptr_table(xs); pz, kz = ptr_table(dzs); pw, kw = ptr_table(dws); pb, kb = ptr_table(dbs)
-    ev = None
-    if TIMER is not None:
-        ev = TIMER.bracket(("convs_wgrad", bool(in_u8), n, B, IH, C, F),
-                           conv_cost("wgrad", bool(in_u8), n, B, IH, IW, C, KH, KW, stride, F))
-        TIMER.rec(ev[0], stream)
     call("serl_convs_wgrad", n, px, pz, pw, pb, workspace, workspace_bytes, int(in_u8), B, IH, IW, C, KH, KW,
          stride, F, stream)
-    if ev is not None:
-        TIMER.rec(ev[1], stream)
 
 
 def convs_wgrad_noalloc(xs, dzs, dws, dbs, in_u8, B, IH, IW, C, KH, KW, stride, F, stream):

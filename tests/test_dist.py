@@ -142,7 +142,7 @@ def test_dp_learner_two_ranks_equals_one(dev, large):
     batch = make_pixel_batch(np.random.default_rng(2), bg * utd, keys, H, W, S, 19, 7, packed=True)
     new, info1 = agent.update(batch, utd, pixel_keys=keys)
     for k in info1:
-        assert abs(info1[k] - info2[k]) <= 1e-3 * max(abs(info1[k]), 1e-2), (k, info1[k], info2[k])
+        assert abs(info1[k] - info2[k]) <= 1e-3 * max(abs(info1[k]), 1e-2), (k, dict(info1), info2)
     g1 = agent._shared["critic_grads"].flat.cpu().numpy()
     assert np.abs(g1 - grads2).max() <= 2e-2 * np.abs(g1).max()       # last UTD step, after one Adam step of drift
     assert np.abs(new.critic.store.flat.cpu().numpy() - critic2).max() <= 2.5 * 3e-4 * 2
