@@ -91,9 +91,23 @@ int serl_sle_bwd(int ngroups, const float* const* dout, int ldo, const float* co
 /* Grouped like the convolutions (<= 8 groups = cameras x passes per launch); dfeat / dker may be NULL tables. */
 /* feat_split != 0: feat / dfeat are S-format tensors (below) instead of fp32. */
 
+/* ---- frozen MobileNetV3-Large feature extractor (inference), the backbone of TwoMobileNetEncoder / MobileNetEncoder:
+ * serl/networks/encoders/two_mobilenet_encoder.py:19-34 ((x - mean) / std, mobilenet.apply(params, x, training=False)),
+ * mobilenet_encoder.py:29-48.  The network comes from the un-vendored jeffnet package in the reference
+ * ('tf_mobilenetv3_large_100'); this is the published architecture with BatchNorm folded, cut after the last 1x1
+ * convolution: features (n, ceil(H/32), ceil(W/32), 960) fp32 NHWC.  params: one flat fp32 buffer of
+ * serl_mbv3_param_floats() floats, leaves in forward order, each 64-float aligned (serl_amd/networks/mobilenet.py).
+ * images: (n,H,W,3) uint8 (divided by 255 on load) or float already in [0,1]; ImageNet normalisation is applied on load. */
+long long serl_mbv3_param_floats(void);
+int serl_mbv3_feature_shape(int H, int W, int* fh, int* fw, int* fc);
+long long serl_mbv3_workspace_bytes(int n, int H, int W);
+int serl_mbv3_forward(const float* params, const void* images, int in_u8, int n, int H, int W, float* workspace,
+                      long long workspace_bytes, float* features, void* stream);
+
 /* ---- batched / segmented dense GEMM: nn.Dense of serl/networks/mlp.py:21-25, pixel_multiplexer.py:34,39, the
  * nn.vmap ensemble of serl/networks/ensemble.py:14-22 (nbatch = members) and their backward products.
- * C[z][m][n] = sum_k A[z][m][k] B[z][k][n] (+bias[z][n]) (relu) ; element strides as named; k = seg*seglen + r. */
+ * C[z][m][n] = sum_k A[z][m][k] B[z][k][n] (+bias[z][n]) (act) ; element strides as named; k = seg*seglen + r;
+ * relu = activation code of the epilogue: 0 none, 1 ReLU, 2 hard-swish, 3 hard-sigmoid. */
 int serl_gemm(const float* a, const float* b, float* c, const float* bias, int nbatch, int M, int N, int K, int seglen,
               long long a_zs, long long a_ss, long long a_ms, long long a_ks, long long b_zs, long long b_ss,
               long long b_ks, long long b_ns, long long c_zs, long long c_ms, long long bias_zs, int nsplit,

@@ -67,6 +67,10 @@ _SIGS = {
     "serl_crop_offsets": [c_u, c_u, c_i, c_i, c_i, c_i, c_p, c_p],
     "serl_prng_randint": [c_u, c_u, c_i, c_i, c_i, c_p, c_p, c_p],
     "serl_take_rows": [c_p, c_ll, c_ll, c_p, c_p, c_i, c_p],
+    "serl_mbv3_param_floats": [],
+    "serl_mbv3_feature_shape": [c_i, c_i, c_p, c_p, c_p],
+    "serl_mbv3_workspace_bytes": [c_i, c_i, c_i],
+    "serl_mbv3_forward": [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_ll, c_p, c_p],
     "serl_learner_create": [c_p, c_p, c_i, c_p, c_i, c_p],
     "serl_learner_destroy": [c_p],
     "serl_learner_update": [c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i],
@@ -84,7 +88,8 @@ _SIGS = {
     "serl_prng_choice": [c_u, c_u, c_i, c_i, c_p],
 }
 _RESTYPE = {"serl_conv2d_wgrad_workspace_bytes": c_ll, "serl_convs_weight_bytes": c_ll,
-            "serl_convs_wgrad_noalloc_max_bytes": c_ll, "serl_learner_workspace_bytes": c_ll}
+            "serl_convs_wgrad_noalloc_max_bytes": c_ll, "serl_learner_workspace_bytes": c_ll, "serl_mbv3_param_floats": c_ll,
+            "serl_mbv3_workspace_bytes": c_ll}
 
 EXPORTS = tuple(_SIGS) + ("serl_last_error",)
 

@@ -76,7 +76,9 @@ struct GemmP {
   }
   __device__ void store(const Ctx& c, const ORow& o, const OCol& oc, int n, int split, float v, float aux) const {
     v += oc.bias + aux;
-    if (g.relu) v = fmaxf(v, 0.f);
+    if (g.relu == 1) v = fmaxf(v, 0.f);                                              // activation code: 1 ReLU,
+    else if (g.relu == 2) v = v * fminf(fmaxf(v + 3.f, 0.f), 6.f) * (1.f / 6.f);     // 2 hard-swish,
+    else if (g.relu == 3) v = fminf(fmaxf(v + 3.f, 0.f), 6.f) * (1.f / 6.f);         // 3 hard-sigmoid (MobileNetV3)
     c.c[split * g.c_ss + o.off + n] = v;
   }
 };

@@ -1,0 +1,293 @@
+// Frozen MobileNetV3-Large feature extractor (inference only) behind TwoMobileNetEncoder / MobileNetEncoder
+// (serl/networks/encoders/two_mobilenet_encoder.py:19-34, mobilenet_encoder.py:29-48).  The reference gets the network
+// from the un-vendored `jeffnet` package ('tf_mobilenetv3_large_100', pretrained); what is implemented is the published
+// architecture of that model name with BatchNorm folded into the convolutions, TensorFlow SAME padding, cut after the
+// last 1x1 convolution (960 channels, stride 32) -- restated on the CPU in oracle/mobilenet.py (parity unpinned for
+// the backbone itself: DESIGN.md).
+//
+// All activations are NHWC fp32.  Per block:  1x1 expand (serl_gemm, bias + ReLU / hard-swish epilogue) -> depthwise
+// k x k (this file: one thread per output pixel x 4 channels, float4, HBM-bound) -> squeeze-excite (mean over the
+// pixels, two tiny GEMMs with ReLU / hard-sigmoid epilogues, channel scaling) -> 1x1 project (serl_gemm; the residual
+// is added by accumulating into the block's input buffer).
+#include <algorithm>
+
+#include "../../include/serl_hip.h"
+#include "common.h"
+
+namespace {
+
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_HSWISH = 2, ACT_HSIGMOID = 3 };
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+  if (act == ACT_RELU) return fmaxf(v, 0.f);
+  if (act == ACT_HSWISH) return v * fminf(fmaxf(v + 3.f, 0.f), 6.f) * (1.f / 6.f);
+  if (act == ACT_HSIGMOID) return fminf(fmaxf(v + 3.f, 0.f), 6.f) * (1.f / 6.f);
+  return v;
+}
+
+struct Blk { int ir, k, s, exp, cout, se, act; };
+constexpr int NBLK = 15, STEM_CH = 16, HEAD_CH = 960;
+const Blk BLOCKS[NBLK] = {
+    {0, 3, 1, 16, 16, 0, ACT_RELU},
+    {1, 3, 2, 64, 24, 0, ACT_RELU},     {1, 3, 1, 72, 24, 0, ACT_RELU},
+    {1, 5, 2, 72, 40, 1, ACT_RELU},     {1, 5, 1, 120, 40, 1, ACT_RELU},    {1, 5, 1, 120, 40, 1, ACT_RELU},
+    {1, 3, 2, 240, 80, 0, ACT_HSWISH},  {1, 3, 1, 200, 80, 0, ACT_HSWISH},  {1, 3, 1, 184, 80, 0, ACT_HSWISH},
+    {1, 3, 1, 184, 80, 0, ACT_HSWISH},  {1, 3, 1, 480, 112, 1, ACT_HSWISH}, {1, 3, 1, 672, 112, 1, ACT_HSWISH},
+    {1, 5, 2, 672, 160, 1, ACT_HSWISH}, {1, 5, 1, 960, 160, 1, ACT_HSWISH}, {1, 5, 1, 960, 160, 1, ACT_HSWISH},
+};
+
+int make_divisible(double v, int d) {
+  int nv = (int)(v + d / 2.0) / d * d;
+  if (nv < d) nv = d;
+  if (nv < 0.9 * v) nv += d;
+  return nv;
+}
+int se_channels(int exp) { return make_divisible(exp * 0.25, 8); }
+void same_pad(int size, int k, int s, int* before, int* out) {   // TensorFlow "SAME"
+  *out = (size + s - 1) / s;
+  int total = (*out - 1) * s + k - size;
+  if (total < 0) total = 0;
+  *before = total / 2;
+}
+
+// ---- stem: ImageNet normalisation + 3x3 stride-2 convolution (3 -> 16) + bias + hard-swish
+// img (n,H,W,3) uint8 (scaled by 1/255) or float already in [0,1]; one thread per output pixel, all 16 channels.
+struct StemArgs {
+  const void* img; const float* w; const float* b; float* y;
+  int n, H, W, OH, OW, pt, pl, in_u8;
+};
+__global__ __launch_bounds__(256) void stem_kernel(const StemArgs a) {
+  __shared__ float sw[27 * STEM_CH + STEM_CH];
+  for (int i = threadIdx.x; i < 27 * STEM_CH + STEM_CH; i += 256) sw[i] = i < 27 * STEM_CH ? a.w[i] : a.b[i - 27 * STEM_CH];
+  __syncthreads();
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long total = (long long)a.n * a.OH * a.OW;
+  if (idx >= total) return;
+  const int ox = (int)(idx % a.OW), oy = (int)((idx / a.OW) % a.OH);
+  const long long img = idx / ((long long)a.OW * a.OH);
+  const float mean[3] = {0.485f, 0.456f, 0.406f}, std[3] = {0.229f, 0.224f, 0.225f};
+  float acc[STEM_CH];
+#pragma unroll
+  for (int f = 0; f < STEM_CH; ++f) acc[f] = sw[27 * STEM_CH + f];
+  for (int ky = 0; ky < 3; ++ky) {
+    const int iy = oy * 2 + ky - a.pt;
+    if (iy < 0 || iy >= a.H) continue;   // zero padding applies to the NORMALISED image
+    for (int kx = 0; kx < 3; ++kx) {
+      const int ix = ox * 2 + kx - a.pl;
+      if (ix < 0 || ix >= a.W) continue;
+      const long long p = ((img * a.H + iy) * a.W + ix) * 3;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        float v = a.in_u8 ? (float)((const unsigned char*)a.img)[p + c] / 255.0f : ((const float*)a.img)[p + c];
+        v = (v - mean[c]) / std[c];
+        const float* wr = sw + ((ky * 3 + kx) * 3 + c) * STEM_CH;
+#pragma unroll
+        for (int f = 0; f < STEM_CH; ++f) acc[f] = fmaf(v, wr[f], acc[f]);
+      }
+    }
+  }
+  float4* out = (float4*)(a.y + idx * STEM_CH);
+#pragma unroll
+  for (int f = 0; f < STEM_CH; f += 4)
+    out[f / 4] = make_float4(act_apply(acc[f], ACT_HSWISH), act_apply(acc[f + 1], ACT_HSWISH),
+                             act_apply(acc[f + 2], ACT_HSWISH), act_apply(acc[f + 3], ACT_HSWISH));
+}
+
+// ---- depthwise k x k convolution + bias + activation, NHWC, SAME padding; thread = (output pixel, 4 channels)
+struct DwArgs {
+  const float* x; const float* w; const float* b; float* y;
+  int n, H, W, C4, OH, OW, k, s, pt, pl, act;
+};
+__global__ __launch_bounds__(256) void dw_kernel(const DwArgs a) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long total = (long long)a.n * a.OH * a.OW * a.C4;
+  if (idx >= total) return;
+  const int c4 = (int)(idx % a.C4);
+  long long p = idx / a.C4;
+  const int ox = (int)(p % a.OW); p /= a.OW;
+  const int oy = (int)(p % a.OH);
+  const long long img = p / a.OH;
+  const float4* x = (const float4*)a.x;
+  const float4* w = (const float4*)a.w;
+  float4 acc = ((const float4*)a.b)[c4];
+  for (int ky = 0; ky < a.k; ++ky) {
+    const int iy = oy * a.s + ky - a.pt;
+    if (iy < 0 || iy >= a.H) continue;
+    for (int kx = 0; kx < a.k; ++kx) {
+      const int ix = ox * a.s + kx - a.pl;
+      if (ix < 0 || ix >= a.W) continue;
+      const float4 v = x[((img * a.H + iy) * a.W + ix) * a.C4 + c4];
+      const float4 ww = w[(ky * a.k + kx) * a.C4 + c4];
+      acc.x = fmaf(v.x, ww.x, acc.x); acc.y = fmaf(v.y, ww.y, acc.y);
+      acc.z = fmaf(v.z, ww.z, acc.z); acc.w = fmaf(v.w, ww.w, acc.w);
+    }
+  }
+  ((float4*)a.y)[idx] = make_float4(act_apply(acc.x, a.act), act_apply(acc.y, a.act), act_apply(acc.z, a.act),
+                                    act_apply(acc.w, a.act));
+}
+
+// ---- squeeze: out[img][c] = mean over the HW pixels; block = (image, 64 channels), 4 pixel phases x 64 channels
+__global__ __launch_bounds__(256) void se_pool_kernel(const float* x, float* out, int HW, int C) {
+  __shared__ float red[4][64];
+  const int img = blockIdx.x, c = blockIdx.y * 64 + (threadIdx.x & 63), ph = threadIdx.x >> 6;
+  float s = 0.f;
+  if (c < C)
+    for (int p = ph; p < HW; p += 4) s += x[((long long)img * HW + p) * C + c];
+  red[ph][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (ph == 0 && c < C) out[(long long)img * C + c] = (red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]) / (float)HW;
+}
+// ---- excite: x[img][p][c] *= gate[img][c], float4
+__global__ __launch_bounds__(256) void se_scale_kernel(float* x, const float* gate, long long total4, int HW, int C4) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total4) return;
+  const int c4 = (int)(idx % C4);
+  const long long img = idx / ((long long)C4 * HW);
+  float4 v = ((float4*)x)[idx];
+  const float4 g = ((const float4*)gate)[img * C4 + c4];
+  v.x *= g.x; v.y *= g.y; v.z *= g.z; v.w *= g.w;
+  ((float4*)x)[idx] = v;
+}
+
+// pointwise convolution / dense layer: Y (M, N) [+]= act(X (M, K) W (K, N) + bias)
+int pointwise(const float* x, const float* w, const float* b, float* y, long long M, int K, int N, int act, int accumulate,
+              hipStream_t st) {
+  SERL_CHECK_ARG(M * (long long)(K > N ? K : N) < (1ll << 31), "mobilenet: chunk too large for 32-bit tensor offsets");
+  return serl_gemm(x, w, y, b, 1, (int)M, N, K, K, 0, 0, K, 1, 0, 0, N, 1, 0, N, 0, 1, 0, act, accumulate, 1, 1, st);
+}
+
+struct Offsets { long long stem_k, stem_b, exp_k[NBLK], exp_b[NBLK], dw_k[NBLK], dw_b[NBLK], ser_k[NBLK], ser_b[NBLK],
+                 see_k[NBLK], see_b[NBLK], pr_k[NBLK], pr_b[NBLK], head_k, head_b; };
+constexpr int ALIGN = 64;   // floats: leaves are laid out like serl_amd/networks/params.py (256-byte aligned)
+long long round_up(long long n) { return (n + ALIGN - 1) / ALIGN * ALIGN; }
+long long layout(Offsets* o) {
+  long long at = 0;
+  auto add = [&](long long n) { long long r = at; at += round_up(n); return r; };
+  o->stem_k = add(27 * STEM_CH); o->stem_b = add(STEM_CH);
+  int cin = STEM_CH;
+  for (int i = 0; i < NBLK; ++i) {
+    const Blk& b = BLOCKS[i];
+    if (b.ir) { o->exp_k[i] = add((long long)cin * b.exp); o->exp_b[i] = add(b.exp); }
+    o->dw_k[i] = add((long long)b.k * b.k * b.exp); o->dw_b[i] = add(b.exp);
+    if (b.se) {
+      const int r = se_channels(b.exp);
+      o->ser_k[i] = add((long long)b.exp * r); o->ser_b[i] = add(r);
+      o->see_k[i] = add((long long)r * b.exp); o->see_b[i] = add(b.exp);
+    }
+    o->pr_k[i] = add((long long)b.exp * b.cout); o->pr_b[i] = add(b.cout);
+    cin = b.cout;
+  }
+  o->head_k = add((long long)cin * HEAD_CH); o->head_b = add(HEAD_CH);
+  return at;
+}
+
+// per-image workspace (floats): two block input/output buffers, the expanded tensor, the depthwise output, SE vectors
+struct Plan { long long x, e, d, se; int fh, fw; };
+int plan(int H, int W, Plan* pl) {
+  int pb, h, w;
+  same_pad(H, 3, 2, &pb, &h);
+  same_pad(W, 3, 2, &pb, &w);
+  long long mx = (long long)h * w * STEM_CH, me = 0, md = 0;
+  int cin = STEM_CH;
+  for (int i = 0; i < NBLK; ++i) {
+    const Blk& b = BLOCKS[i];
+    if (b.ir) me = std::max(me, (long long)h * w * b.exp);
+    int oh, ow;
+    same_pad(h, b.k, b.s, &pb, &oh);
+    same_pad(w, b.k, b.s, &pb, &ow);
+    md = std::max(md, (long long)oh * ow * b.exp);
+    mx = std::max(mx, (long long)oh * ow * b.cout);
+    h = oh; w = ow; cin = b.cout;
+  }
+  (void)cin;
+  pl->x = round_up(mx); pl->e = round_up(me); pl->d = round_up(md); pl->se = round_up(960) * 3;
+  pl->fh = h; pl->fw = w;
+  return SERL_OK;
+}
+
+}  // namespace
+
+extern "C" long long serl_mbv3_param_floats(void) {
+  Offsets o;
+  return layout(&o);
+}
+extern "C" int serl_mbv3_feature_shape(int H, int W, int* fh, int* fw, int* fc) {
+  SERL_CHECK_ARG(H >= 32 && W >= 32 && fh && fw && fc, "mbv3_feature_shape: images must be at least 32x32");
+  Plan pl;
+  plan(H, W, &pl);
+  *fh = pl.fh; *fw = pl.fw; *fc = HEAD_CH;
+  return SERL_OK;
+}
+extern "C" long long serl_mbv3_workspace_bytes(int n, int H, int W) {
+  if (n < 1 || H < 32 || W < 32) return -1;
+  Plan pl;
+  plan(H, W, &pl);
+  return (long long)n * (2 * pl.x + pl.e + pl.d + pl.se) * 4;
+}
+
+extern "C" int serl_mbv3_forward(const float* params, const void* images, int in_u8, int n, int H, int W, float* workspace,
+                                 long long workspace_bytes, float* features, void* stream) {
+  SERL_CHECK_ARG(params && images && workspace && features && n >= 1, "mbv3_forward: bad args");
+  SERL_CHECK_ARG(H >= 32 && W >= 32, "mbv3_forward: images must be at least 32x32");
+  const long long need = serl_mbv3_workspace_bytes(n, H, W);
+  SERL_CHECK_ARG(workspace_bytes >= need, "mbv3_forward: workspace needs %lld bytes, %lld given", need, workspace_bytes);
+  SERL_CHECK_ARG((((uintptr_t)params | (uintptr_t)workspace | (uintptr_t)features) & 15) == 0, "mbv3_forward: buffers must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  Offsets o;
+  layout(&o);
+  Plan pl;
+  plan(H, W, &pl);
+  float* X[2] = {workspace, workspace + (long long)n * pl.x};
+  float* E = X[1] + (long long)n * pl.x;
+  float* D = E + (long long)n * pl.e;
+  float* pooled = D + (long long)n * pl.d;
+  float* reduced = pooled + (long long)n * round_up(960);
+  float* gate = reduced + (long long)n * round_up(960);
+  int h, w, pt, pl_;
+  same_pad(H, 3, 2, &pt, &h);
+  same_pad(W, 3, 2, &pl_, &w);
+  {
+    StemArgs a{images, params + o.stem_k, params + o.stem_b, X[0], n, H, W, h, w, pt, pl_, in_u8};
+    const long long total = (long long)n * h * w;
+    hipLaunchKernelGGL(stem_kernel, dim3((unsigned)cdivll(total, 256)), dim3(256), 0, st, a);
+    SERL_CHECK_LAUNCH("mbv3 stem");
+  }
+  int cur = 0, cin = STEM_CH;
+  for (int i = 0; i < NBLK; ++i) {
+    const Blk& b = BLOCKS[i];
+    const long long M = (long long)n * h * w;
+    const float* xin = X[cur];
+    const float* dwin = xin;
+    if (b.ir) {
+      if (int e = pointwise(xin, params + o.exp_k[i], params + o.exp_b[i], E, M, cin, b.exp, b.act, 0, st)) return e;
+      dwin = E;
+    }
+    int oh, ow;
+    same_pad(h, b.k, b.s, &pt, &oh);
+    same_pad(w, b.k, b.s, &pl_, &ow);
+    {
+      DwArgs a{dwin, params + o.dw_k[i], params + o.dw_b[i], D, n, h, w, b.exp / 4, oh, ow, b.k, b.s, pt, pl_, b.act};
+      const long long total = (long long)n * oh * ow * (b.exp / 4);
+      hipLaunchKernelGGL(dw_kernel, dim3((unsigned)cdivll(total, 256)), dim3(256), 0, st, a);
+      SERL_CHECK_LAUNCH("mbv3 depthwise");
+    }
+    const long long Mo = (long long)n * oh * ow;
+    if (b.se) {
+      const int r = se_channels(b.exp);
+      hipLaunchKernelGGL(se_pool_kernel, dim3(n, cdiv(b.exp, 64)), dim3(256), 0, st, D, pooled, oh * ow, b.exp);
+      SERL_CHECK_LAUNCH("mbv3 se pool");
+      if (int e = pointwise(pooled, params + o.ser_k[i], params + o.ser_b[i], reduced, n, b.exp, r, ACT_RELU, 0, st)) return e;
+      if (int e = pointwise(reduced, params + o.see_k[i], params + o.see_b[i], gate, n, r, b.exp, ACT_HSIGMOID, 0, st)) return e;
+      const long long total4 = Mo * (b.exp / 4);
+      hipLaunchKernelGGL(se_scale_kernel, dim3((unsigned)cdivll(total4, 256)), dim3(256), 0, st, D, gate, total4, oh * ow,
+                         b.exp / 4);
+      SERL_CHECK_LAUNCH("mbv3 se scale");
+    }
+    const bool residual = b.s == 1 && cin == b.cout;
+    float* xout = residual ? X[cur] : X[cur ^ 1];      // residual: accumulate onto the block's input in place
+    if (int e = pointwise(D, params + o.pr_k[i], params + o.pr_b[i], xout, Mo, b.exp, b.cout, ACT_NONE, residual, st)) return e;
+    if (!residual) cur ^= 1;
+    h = oh; w = ow; cin = b.cout;
+  }
+  return pointwise(X[cur], params + o.head_k, params + o.head_b, features, (long long)n * h * w, cin, HEAD_CH, ACT_HSWISH, 0, st);
+}

@@ -1,0 +1,50 @@
+"""Frozen MobileNetV3-Large backbone (csrc/mobilenet.hip) vs the CPU restatement (oracle/mobilenet.py) on the same
+synthetic weights.  The backbone itself is parity-unpinned against the reference (jeffnet + pretrained weights are
+unavailable offline); this pins the HIP kernels to the restated architecture: TF SAME padding with stride 2,
+depthwise 3x3 / 5x5, squeeze-excite, hard-swish / hard-sigmoid, residuals."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_layout_matches_the_library():
+    from oracle import mobilenet as om
+    from serl_amd.networks import mobilenet as pm
+    assert [(n, tuple(s)) for n, s in om.leaf_shapes()] == [(n, tuple(s)) for n, s in pm.leaf_shapes()]
+    from serl_amd import _lib
+    assert pm._offsets()[1] == _lib.load().serl_mbv3_param_floats()
+
+
+@pytest.mark.parametrize("case", [(3, 128, 128, "u8"), (2, 128, 128, "f32"), (2, 96, 80, "u8"), (1, 224, 224, "f32")])
+def test_backbone_matches_oracle(dev, case, prec):
+    from oracle import mobilenet as om
+    from serl_amd.networks.mobilenet import Backbone
+    n, H, W, kind = case
+    bb = Backbone.synthetic(3)
+    params = bb.tree()
+    rng = np.random.default_rng(n * H + W)
+    u8 = rng.integers(0, 256, size=(n, H, W, 3), dtype=np.uint8)
+    img01 = u8.astype(np.float32) / np.float32(255.0)
+    x = torch.from_numpy(u8 if kind == "u8" else img01).to(dev)
+    got = bb.forward(x).cpu().numpy()
+    want = om.forward(params, om.normalize(torch.tensor(img01, dtype=torch.float64)).numpy(), dtype=torch.float64).numpy()
+    assert got.shape == want.shape == (n, -(-H // 32), -(-W // 32), 960)
+    scale = np.abs(want).max()
+    tol = (2e-5 if prec == "highest" else 2e-4) * scale
+    assert np.isfinite(got).all() and scale > 1e-2
+    assert np.abs(got - want).max() <= tol, (np.abs(got - want).max(), scale)
+
+
+def test_backbone_chunks_and_from_tree(dev):
+    from serl_amd.networks.mobilenet import Backbone
+    bb = Backbone.synthetic(1)
+    bb2 = Backbone.from_tree(bb.tree())
+    assert torch.equal(bb.flat, bb2.flat)
+    x = torch.randint(0, 256, (5, 64, 64, 3), dtype=torch.uint8, device=dev)
+    full = bb.forward(x)
+    bb2.CHUNK = 2
+    assert torch.equal(bb2.forward(x), full)
+    with pytest.raises(TypeError):
+        bb.forward(x.to(torch.int32))
