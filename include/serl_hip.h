@@ -153,6 +153,12 @@ int serl_rowdot(const float* h, const float* w, long long w_group_stride, const 
 int serl_copy2d(float* dst, int ldd, const float* src, int lds, int rows, int cols, void* stream); /* jnp.concatenate */
 int serl_fill(float* p, float v, long long n, void* stream);
 
+/* nn.Dropout in training mode on a (rows, cols) block with row stride ld, in place (applied to the gradient with the
+ * same key in the backward pass): serl/networks/encoders/two_mobilenet_encoder.py:34, encoded_encoder.py:34.
+ * keep = jax.random.bernoulli(key, keep_prob, (total_rows, cols))[row_offset + r][c]. */
+int serl_dropout(float* x, int ld, int rows, int cols, unsigned k0, unsigned k1, float keep_prob, int row_offset,
+                 int total_rows, void* stream);
+
 /* ---- tanh-Gaussian policy head, serl/distributions/tanh_normal.py:29-48 + TFP MultivariateNormalDiag/Tanh;
  * eps = jax.random.normal(key, (total_rows, A))[row_offset : row_offset + B] (threefry2x32, XLA erf_inv). */
 int serl_tanh_gaussian_fwd(const float* mean, const float* log_std_raw, int ld_ms, float* act, int ld_act, float* xpre,
@@ -198,6 +204,7 @@ int serl_take_rows(const void* src, long long nrows, long long row_bytes, const 
 int serl_prng_split(unsigned k0, unsigned k1, int num, unsigned* out);
 int serl_prng_bits(unsigned k0, unsigned k1, int n, unsigned* out);
 int serl_prng_choice(unsigned k0, unsigned k1, int n, int m, int* out);
+int serl_prng_fold_in(unsigned k0, unsigned k1, unsigned data, unsigned* out);
 
 /* ==== Native step driver: one call per update() / per action (serl_amd/csrc/driver.hip).
  * The coarse boundary of SURVEY.md 8(b): Python holds handles and pointers, every launch, stream, event and per-step
@@ -221,6 +228,9 @@ typedef struct {
   int cnn_features[8], cnn_filters[8], cnn_strides[8];
   int aug_rank[4];             /* position of the i-th camera (sorted-key order) in the caller's pixel_keys order */
   float discount, tau, target_entropy, actor_lr, critic_lr, temp_lr;
+  int encoder;                 /* 0 TwoD4PGEncoder (trainable conv stack), 1 TwoMobileNetEncoder (frozen backbone, stack 1) */
+  int feat_h, feat_w, feat_c;  /* encoder 1: serl_mbv3_feature_shape(height, width) */
+  float encoder_dropout;       /* encoder 1: Dropout rate behind the spatial embeddings in training passes (0.1) */
 } serl_learner_config;
 /* flat fp32 device buffers of ONE agent copy (parameters, Adam moments, temperature state {log_temp, mu, nu}) plus the
  * gradient buffers (same layouts); update() steps them in place -- the caller clones first to keep the old agent valid */
@@ -250,6 +260,8 @@ typedef int (*serl_allreduce_fn)(void* ctx, int which);
 int serl_learner_create(const serl_learner_config* cfg, const long long* critic_offsets, int n_critic,
                         const long long* actor_offsets, int n_actor, serl_learner** out);
 int serl_learner_destroy(serl_learner* h);
+/* encoder 1: the frozen backbone's parameters (device, serl_mbv3_param_floats floats); must outlive the handle's use */
+int serl_learner_set_backbone(serl_learner* h, const float* params);
 /* rng_in / rng_out: jax key (uint32[2]) before / after the call; info_out: 8 device floats {critic loss sum, q sum,
  * actor loss sum, logp sum, temperature, temperature loss, entropy, -}; everything is enqueued on `stream` and the
  * handle's own streams, nothing waits for the GPU */

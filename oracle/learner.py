@@ -127,9 +127,39 @@ def two_d4pg_encoder(p, images, strides):
     return torch.cat(outs, -1)
 
 
-def pixel_trunk(p, obs, cfg, dtype):
+def encoder_dropout(x, key, ci, rate, shard=None):
+    """nn.Dropout(rate)(x, deterministic=False) behind camera ci's SpatialLearnedEmbeddings
+    (two_mobilenet_encoder.py:34): where(bernoulli(rng, 1 - rate, x.shape), x / (1 - rate), 0).  flax derives `rng`
+    from rngs={"dropout": key} by folding in the module path (not restatable without flax): BUILD-DEFINED here as
+    fold_in(key, ci) -- parity unpinned for the mask stream.  With shard=(row_offset, total_rows) the rows are
+    rows [row_offset, row_offset + B) of the (total_rows, F) draw (data parallel: keyed by the global row)."""
+    keep = np.float32(1.0 - rate)
+    B, Fd = x.shape
+    off, total = shard if shard is not None else (0, B)
+    mask = prng.bernoulli(prng.fold_in(key, ci), keep, (total, Fd))[off:off + B]
+    return torch.where(torch.as_tensor(mask), x / float(keep), torch.zeros_like(x))
+
+
+def two_mobilenet_encoder(p, images01, cfg, dtype, dropout_key=None, shard=None, rate=None):
+    """serl/networks/encoders/two_mobilenet_encoder.py:15-45: per camera (sorted keys) ImageNet-normalise the /255 image,
+    frozen backbone (no gradient), SpatialLearnedEmbeddings(..., 8), Dropout(rate) when training; concat."""
+    from . import mobilenet as mb
+    outs = []
+    rate = cfg.get("encoder_dropout", 0.1) if rate is None else rate
+    for ci, key in enumerate(sorted(images01)):
+        with torch.no_grad():
+            feat = mb.forward(cfg["backbone"], mb.normalize(images01[key].to(torch.float32)).numpy(), dtype=dtype)
+        t = sle(p[f"SpatialLearnedEmbeddings_{ci}"], feat)
+        if dropout_key is not None:
+            t = encoder_dropout(t, dropout_key, ci, rate, shard)
+        outs.append(t)
+    return torch.cat(outs, -1)
+
+
+def pixel_trunk(p, obs, cfg, dtype, dropout_key=None, shard=None):
     """serl/networks/pixel_multiplexer.py:25-45 up to the concat. obs: dict with 'state'
-    and uint8 pixel leaves (B,H,W,3,S)."""
+    and uint8 pixel leaves (B,H,W,3,S).  dropout_key: rngs={"dropout": key} of an apply call with training=True (only
+    the MobileNet encoder has a Dropout layer)."""
     images = {}
     for k in obs:
         if k == "state":
@@ -137,6 +167,8 @@ def pixel_trunk(p, obs, cfg, dtype):
         x = torch.as_tensor(np.asarray(obs[k]))
         x = x.reshape(*x.shape[:-2], -1).to(torch.float32) / 255.0     # :27
         images[k] = x.to(dtype)
+    if cfg.get("encoder", "d4pg") == "mobilenet":
+        return two_mobilenet_encoder(p["image_encoder"], images, cfg, dtype, dropout_key, shard)
     x = two_d4pg_encoder(p["image_encoder"], images, cfg["cnn_strides"])
     return x
 
@@ -167,9 +199,9 @@ def actor_dist(p, obs, cfg, dtype):
     return mean, log_std
 
 
-def critic_qs(p, obs, actions, cfg, dtype):
+def critic_qs(p, obs, actions, cfg, dtype, dropout_key=None, shard=None):
     if _is_pixel(cfg):
-        enc = pixel_trunk(p, obs, cfg, dtype)
+        enc = pixel_trunk(p, obs, cfg, dtype, dropout_key, shard)
         st = torch.as_tensor(np.asarray(obs["state"]), dtype=dtype)
         z = pixel_latent(p, enc, st)
         ep = p["Ensemble_0"]["VmapStateActionValue_0"]
@@ -264,8 +296,8 @@ def update_critic(state, cfg, batch, dtype=torch.float32, shard=None):
         key, rng = prng.split(rng)
         tparams, indx = subsample_ensemble(key, state["target_critic"]["params"],
                                            cfg["num_min_qs"], cfg["num_qs"])     # :172-175
-        key, rng = prng.split(rng)                                               # dropout key (unused)
-        next_qs = critic_qs(to_torch(tparams, dtype), batch["next_observations"], next_a, cfg, dtype)
+        key, rng = prng.split(rng)                                               # dropout key of the target apply (:177-184)
+        next_qs = critic_qs(to_torch(tparams, dtype), batch["next_observations"], next_a, cfg, dtype, key, shard)
         next_q = next_qs.min(0).values                                           # :185
         rew = torch.as_tensor(np.asarray(batch["rewards"]), dtype=dtype)
         msk = torch.as_tensor(np.asarray(batch["masks"]), dtype=dtype)
@@ -274,11 +306,11 @@ def update_critic(state, cfg, batch, dtype=torch.float32, shard=None):
             nlp = tanh_normal_log_prob(mean, log_std, next_x)
             alpha = math.exp(float(state["temp"]["params"]["log_temp"]))
             target_q = target_q - cfg["discount"] * msk * alpha * nlp            # :189-196
-    key, rng = prng.split(rng)                                                   # :198
+    key, rng = prng.split(rng)                                                   # :198 dropout key of the critic apply
 
     cp = to_torch(state["critic"]["params"], dtype, requires_grad=True)
     act = torch.as_tensor(np.asarray(batch["actions"]), dtype=dtype)
-    qs = critic_qs(cp, batch["observations"], act, cfg, dtype)
+    qs = critic_qs(cp, batch["observations"], act, cfg, dtype, key, shard)
     loss = ((qs - target_q) ** 2).mean()                                          # :208
     if shard is not None:
         loss = ((qs - target_q) ** 2).sum() / (qs.shape[0] * shard[1])
@@ -316,7 +348,7 @@ def update_actor(state, cfg, batch, dtype=torch.float32):
     mean, log_std = actor_dist(ap, batch["observations"], cfg, dtype)
     a, x = tanh_normal_sample(mean, log_std, key)
     logp = tanh_normal_log_prob(mean, log_std, x)
-    qs = critic_qs(cp, batch["observations"], a, cfg, dtype)
+    qs = critic_qs(cp, batch["observations"], a, cfg, dtype, key2)              # :129-134 training=True, dropout=key2
     q = qs.mean(0)                                                               # :135
     alpha = math.exp(float(state["temp"]["params"]["log_temp"]))
     loss = (logp * alpha - q).mean()                                             # :136-138

@@ -140,6 +140,16 @@ def normal(key, shape) -> np.ndarray:
     return (np.float32(math.sqrt(2.0)) * erfinv_f32(u)).astype(np.float32)
 
 
+def fold_in(key, data: int) -> np.ndarray:
+    """jax.random.fold_in(key, data) = threefry_2x32(key, threefry_seed(data)) with the 32-bit seed [0, data]."""
+    return threefry_2x32(key, np.array([0, int(data) & 0xFFFFFFFF], dtype=U32))
+
+
+def bernoulli(key, p, shape) -> np.ndarray:
+    """jax.random.bernoulli(key, p, shape) = uniform(key, shape) < p."""
+    return uniform(key, shape) < np.float32(p)
+
+
 def permutation(key, n: int) -> np.ndarray:
     """jax.random.permutation(key, arange(n)): rounds of stable sort by fresh random bits."""
     x = np.arange(n, dtype=np.int32)

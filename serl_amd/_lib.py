@@ -73,6 +73,7 @@ _SIGS = {
     "serl_mbv3_forward": [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_ll, c_p, c_p],
     "serl_learner_create": [c_p, c_p, c_i, c_p, c_i, c_p],
     "serl_learner_destroy": [c_p],
+    "serl_learner_set_backbone": [c_p, c_p],
     "serl_learner_update": [c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i],
     "serl_learner_act": [c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p],
     "serl_learner_read_buffer": [c_p, c_i, C.c_char_p, c_p, c_ll, c_p],
@@ -86,6 +87,8 @@ _SIGS = {
     "serl_prng_split": [c_u, c_u, c_i, c_p],
     "serl_prng_bits": [c_u, c_u, c_i, c_p],
     "serl_prng_choice": [c_u, c_u, c_i, c_i, c_p],
+    "serl_prng_fold_in": [c_u, c_u, c_u, c_p],
+    "serl_dropout": [c_p, c_i, c_i, c_i, c_u, c_u, c_f, c_i, c_i, c_p],
 }
 _RESTYPE = {"serl_conv2d_wgrad_workspace_bytes": c_ll, "serl_convs_weight_bytes": c_ll,
             "serl_convs_wgrad_noalloc_max_bytes": c_ll, "serl_learner_workspace_bytes": c_ll, "serl_mbv3_param_floats": c_ll,

@@ -28,14 +28,15 @@ class PixelDDPGLearner(DrQLearner):
                cnn_strides: Sequence[int] = (2, 1, 1, 1), cnn_padding: str = "VALID", latent_dim: int = 50,
                encoder: str = "d4pg", hidden_dims: Sequence[int] = (256, 256), discount: float = 0.99,
                tau: float = 0.005, critic_dropout_rate: Optional[float] = None, critic_layer_norm: bool = False,
-               pixel_keys: Tuple[str, ...] = ("pixels",), depth_keys: Tuple[str, ...] = (), device=None, dist=None):
+               pixel_keys: Tuple[str, ...] = ("pixels",), depth_keys: Tuple[str, ...] = (), device=None, dist=None,
+               backbone=None):
         cfg = cls._pixel_cfg(observation_space, action_space, cnn_features, cnn_filters, cnn_strides, cnn_padding,
                              latent_dim, encoder, hidden_dims, 1, critic_layer_norm, pixel_keys, depth_keys)
         self = cls._build(cfg, seed, actor_lr, critic_lr, 0.0, discount, tau, None, critic_dropout_rate, 0.0, 1.0,
                           False, device, dist, nkeys=3)                       # rng, actor_key, critic_key (:59)
         dev = self.actor.store.flat.device
         self.temp = TempState(torch.tensor([float("-inf"), 0.0, 0.0], dtype=torch.float32, device=dev), 0, 0.0)
-        return self
+        return self._attach_backbone(backbone)      # encoder="mobilenet" (pixel_ddpg_learner.py:78-83)
 
     # key, rng = split(rng) for the two augmentation keys (:169,171), and the DDPG update runs on new_agent, whose rng
     # was never replaced (:180): evaluated by the native driver (aug_mode 2, driver.hip serl_learner_update)

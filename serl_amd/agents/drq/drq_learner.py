@@ -36,18 +36,34 @@ class DrQLearner(SACLearner):
                num_min_qs: Optional[int] = None, critic_dropout_rate: Optional[float] = None,
                critic_layer_norm: bool = False, target_entropy: Optional[float] = None,
                init_temperature: float = 1.0, backup_entropy: bool = True, pixel_keys: Tuple[str, ...] = ("pixels",),
-               depth_keys: Tuple[str, ...] = (), device=None, dist=None):
+               depth_keys: Tuple[str, ...] = (), device=None, dist=None, backbone=None):
+        """`backbone` (extra keyword, encoder="mobilenet" only): a serl_amd.networks.mobilenet.Backbone holding the frozen
+        MobileNetV3-Large weights.  The reference downloads pretrained ones through jeffnet (drq_classifier_reward_
+        learner.py:94-98), which is impossible offline: without the keyword a synthetic backbone is used."""
         cfg = cls._pixel_cfg(observation_space, action_space, cnn_features, cnn_filters, cnn_strides, cnn_padding,
                              latent_dim, encoder, hidden_dims, num_qs, critic_layer_norm, pixel_keys, depth_keys)
-        return cls._build(cfg, seed, actor_lr, critic_lr, temp_lr, discount, tau, num_min_qs, critic_dropout_rate,
+        self = cls._build(cfg, seed, actor_lr, critic_lr, temp_lr, discount, tau, num_min_qs, critic_dropout_rate,
                           target_entropy, init_temperature, backup_entropy, device, dist)
+        return self._attach_backbone(backbone)
+
+    def _attach_backbone(self, backbone):
+        if self._cfg.encoder == "mobilenet":
+            from ...networks.mobilenet import Backbone
+            dev = self.actor.store.flat.device
+            if backbone is None:
+                backbone = Backbone.synthetic(0, device=dev)
+            self._shared["backbone"] = backbone
+            self._native.set_backbone(backbone)
+        elif backbone is not None:
+            raise ValueError("backbone= is only used with encoder='mobilenet'")
+        return self
 
     @staticmethod
     def _pixel_cfg(observation_space, action_space, cnn_features, cnn_filters, cnn_strides, cnn_padding, latent_dim,
                    encoder, hidden_dims, num_qs, critic_layer_norm, pixel_keys, depth_keys):
-        if encoder != "d4pg":
-            raise NotImplementedError(f"encoder={encoder!r}: only the d4pg conv encoder is on the hot path")
-        if cnn_padding != "VALID":
+        if encoder not in ("d4pg", "mobilenet"):    # "resnet": the reference's branch references undefined classes
+            raise NotImplementedError(f"encoder={encoder!r}: 'd4pg' (TwoD4PGEncoder) or 'mobilenet' (TwoMobileNetEncoder)")
+        if encoder == "d4pg" and cnn_padding != "VALID":
             raise NotImplementedError("only VALID padding (every SERL config)")
         if depth_keys:
             raise NotImplementedError("depth_keys are not used by any SERL config")
@@ -60,11 +76,20 @@ class DrQLearner(SACLearner):
         extra = set(observation_space.spaces) - set(pixel_keys) - {"state"}
         if extra:
             raise NotImplementedError(f"unsupported extra observation keys {sorted(extra)}")
-        return NetConfig(action_dim=int(action_space.shape[-1]), hidden_dims=tuple(int(h) for h in hidden_dims),
-                        num_qs=int(num_qs), critic_layer_norm=bool(critic_layer_norm), pixel_keys=pixel_keys,
-                        state_dim=int(observation_space.spaces["state"].shape[-1]), H=int(H), W=int(W), stack=int(S),
-                        cnn_features=tuple(cnn_features), cnn_filters=tuple(cnn_filters),
-                        cnn_strides=tuple(cnn_strides), latent_dim=int(latent_dim))
+        kw = dict(action_dim=int(action_space.shape[-1]), hidden_dims=tuple(int(h) for h in hidden_dims),
+                  num_qs=int(num_qs), critic_layer_norm=bool(critic_layer_norm), pixel_keys=pixel_keys,
+                  state_dim=int(observation_space.spaces["state"].shape[-1]), H=int(H), W=int(W), stack=int(S),
+                  latent_dim=int(latent_dim))
+        if encoder == "mobilenet":
+            # frozen MobileNetV3 features -> SpatialLearnedEmbeddings -> Dropout(0.1) (two_mobilenet_encoder.py:10-45);
+            # the backbone takes 3-channel images, i.e. frame stack 1 (every shipped script: FrameStack(env, 1))
+            if S != 1:
+                raise ValueError("encoder='mobilenet' needs pixel observations of shape (H, W, 3, 1)")
+            from ...networks.mobilenet import Backbone
+            fh, fw, fc = Backbone.feature_shape(H, W)
+            return NetConfig(encoder="mobilenet", feat_h=fh, feat_w=fw, feat_c=fc, **kw)
+        return NetConfig(cnn_features=tuple(cnn_features), cnn_filters=tuple(cnn_filters),
+                         cnn_strides=tuple(cnn_strides), **kw)
 
     # ------------------------------------------------------------------ pixel leaves -> device pointers
     def _pixel_sources(self, batch, n, ub: UpdateBatch, keep):

@@ -45,6 +45,14 @@ extern "C" int serl_prng_split(unsigned k0, unsigned k1, int num, unsigned* out)
   for (int i = 0; i < 2 * num; ++i) out[i] = threefry_bits_at(k0, k1, (uint32_t)i, (uint32_t)(2 * num));
   return SERL_OK;
 }
+// jax.random.fold_in(key, data) = threefry_2x32(key, [0, data])
+extern "C" int serl_prng_fold_in(unsigned k0, unsigned k1, unsigned data, unsigned* out) {
+  SERL_CHECK_ARG(out, "prng_fold_in: bad args");
+  uint32_t x0 = 0, x1 = data;
+  threefry2x32(k0, k1, x0, x1);
+  out[0] = x0; out[1] = x1;
+  return SERL_OK;
+}
 // jax.random.bits(key, (n,), uint32)
 extern "C" int serl_prng_bits(unsigned k0, unsigned k1, int n, unsigned* out) {
   SERL_CHECK_ARG(out && n >= 1, "prng_bits: bad args");

@@ -46,6 +46,9 @@ struct Cfg {
   int obs_dim;                                   // state-based
   int ncam, H, W, stack, state_dim, latent_dim;  // pixel-based
   int nl; ConvL L[MAX_CONV];
+  int encoder;             // 0 TwoD4PGEncoder (trainable conv stack), 1 TwoMobileNetEncoder (frozen backbone + SLE + Dropout)
+  int fh, fw, fc;          // feature map the spatial embeddings pool (mobilenet: backbone output; d4pg: last conv layer)
+  float enc_drop;          // Dropout rate behind the spatial embeddings (mobilenet encoder, training passes only)
   int aug_rank[MAX_CAM];   // position of (sorted) camera ci in the caller's pixel_keys order: augmentation key order
   float discount, tau, target_entropy, actor_lr, critic_lr, temp_lr;
   int enc_dim, latent, ldz;
@@ -153,6 +156,7 @@ struct serl_learner {
   GradSide gside;
   hipEvent_t fork_ev = nullptr, join1 = nullptr, astart = nullptr, agate = nullptr, aobs = nullptr;
   std::vector<hipEvent_t> adone;
+  const float* backbone = nullptr;   // frozen MobileNetV3 parameters (serl_learner_set_backbone)
   // instrumentation
   bool timing = false, phases = false;
   std::vector<TimeRec> trecs;
@@ -723,8 +727,42 @@ struct Feats {   // device inputs of the call, rows [0, n)
   const float* obs = nullptr; const float* next_obs = nullptr;         // state-based: (n, obs_dim)
   const float* state = nullptr; const float* next_state = nullptr;     // pixel-based: (n, state_dim)
   unsigned char* aug[2][MAX_CAM] = {};                                 // [obs|next][sorted cam] (n, H, W, 3*S) uint8
+  float* bb[2][MAX_CAM] = {};                                          // mobilenet encoder: backbone features (n, fh, fw, fc)
+  int row0 = 0, total_rows = 0;                                        // global row of this rank's minibatch row 0 / global minibatch
 };
-struct FPass { char tag; Store store; const EncOff* eo; int which; float* z; hipStream_t trunk_stream; };   // which: 0 obs, 1 next
+// which: 0 obs, 1 next; drop: rngs={"dropout": key} of an apply call with training=True (NULL: no dropout)
+struct FPass { char tag; Store store; const EncOff* eo; int which; float* z; hipStream_t trunk_stream; const uint32_t* drop = nullptr; };
+
+// TwoMobileNetEncoder behind its frozen backbone (two_mobilenet_encoder.py:33-34): SpatialLearnedEmbeddings of the
+// minibatch rows of every pass (one grouped launch), then Dropout for the training passes.  The Dropout rng: flax folds
+// the module path into rngs["dropout"] (not restatable); BUILD-DEFINED as fold_in(key, camera index), mask element =
+// bernoulli bits of the (global minibatch, C*8) draw at the GLOBAL row (oracle/learner.py encoder_dropout).
+int mobilenet_sle_fwd(serl_learner* h, const FPass* passes, int npass, const Feats& f, int lo, int B, Workspace& ws, hipStream_t st) {
+  const Cfg& c = h->cfg;
+  const int HW = c.fh * c.fw, F8 = c.fc * SLE_FEATURES;
+  const void* feats[MAXG_]; const float* kers[MAXG_]; float* outs[MAXG_];
+  int n = 0;
+  SERL_CHECK_ARG(npass * c.ncam <= MAXG_, "learner: too many (pass, camera) groups");
+  for (int i = 0; i < npass; ++i) {
+    WSF(ws, st, enc, (size_t)B * c.enc_dim, "enc_%c", passes[i].tag);
+    for (int ci = 0; ci < c.ncam; ++ci, ++n) {
+      feats[n] = f.bb[passes[i].which][ci] + (size_t)lo * HW * c.fc;
+      kers[n] = passes[i].store.at(passes[i].eo->sle[ci]);
+      outs[n] = enc + (size_t)ci * F8;
+    }
+  }
+  DRV(serl_sle_fwd(n, feats, kers, outs, c.enc_dim, B, HW, c.fc, SLE_FEATURES, 0, st));
+  for (int i = 0; i < npass; ++i) {
+    if (!passes[i].drop || c.enc_drop <= 0.f) continue;
+    WSF(ws, st, enc, (size_t)B * c.enc_dim, "enc_%c", passes[i].tag);
+    for (int ci = 0; ci < c.ncam; ++ci) {
+      unsigned k[2];
+      DRV(serl_prng_fold_in(passes[i].drop[0], passes[i].drop[1], (unsigned)ci, k));
+      DRV(serl_dropout(enc + (size_t)ci * F8, c.enc_dim, B, F8, k[0], k[1], 1.0f - c.enc_drop, f.row0, f.total_rows, st));
+    }
+  }
+  return SERL_OK;
+}
 
 int features(serl_learner* h, const FPass* passes, int npass, const Feats& f, int lo, int B, Workspace& ws, hipStream_t st,
              char save_tag, hipEvent_t fork, bool prep) {
@@ -738,13 +776,17 @@ int features(serl_learner* h, const FPass* passes, int npass, const Feats& f, in
     }
     return SERL_OK;
   }
-  const size_t img_bytes = (size_t)c.H * c.W * 3 * c.stack;
-  Pass ep[4];
-  for (int i = 0; i < npass; ++i) {
-    ep[i].tag = passes[i].tag; ep[i].store = passes[i].store; ep[i].eo = passes[i].eo;
-    for (int ci = 0; ci < c.ncam; ++ci) ep[i].imgs[ci] = f.aug[passes[i].which][ci] + lo * img_bytes;
+  if (c.encoder == 1) {
+    DRV(mobilenet_sle_fwd(h, passes, npass, f, lo, B, ws, st));
+  } else {
+    const size_t img_bytes = (size_t)c.H * c.W * 3 * c.stack;
+    Pass ep[4];
+    for (int i = 0; i < npass; ++i) {
+      ep[i].tag = passes[i].tag; ep[i].store = passes[i].store; ep[i].eo = passes[i].eo;
+      for (int ci = 0; ci < c.ncam; ++ci) ep[i].imgs[ci] = f.aug[passes[i].which][ci] + lo * img_bytes;
+    }
+    DRV(encoder_fwd(h, ep, npass, B, ws, st, save_tag, prep));
   }
-  DRV(encoder_fwd(h, ep, npass, B, ws, st, save_tag, prep));
   if (fork)     // the trunks of the passes are independent: side streams wait for the encoders
     for (int i = 0; i < npass; ++i) DRV(link(st, passes[i].trunk_stream, fork));
   for (int i = 0; i < npass; ++i) {
@@ -757,13 +799,33 @@ int features(serl_learner* h, const FPass* passes, int npass, const Feats& f, in
 
 int features_bwd(serl_learner* h, char tag, const Store& store, const EncOff& eo, const Store& grads, const Feats& f, int lo,
                  int B, Workspace& ws, hipStream_t st, const float* dz, int lddz, bool need_encoder, GradSide* gside,
-                 int dz_nslab, long long dz_ss) {
+                 int dz_nslab, long long dz_ss, const uint32_t* drop = nullptr) {
   const Cfg& c = h->cfg;
   if (!c.pixel) return SERL_OK;   // no trainable feature stage for state inputs
   WSF(ws, st, z, (size_t)B * c.ldz, "z%c", tag);
   DRV(trunk_bwd(h, tag, store, eo, grads, f.state + (size_t)lo * c.state_dim, z, c.ldz, dz, lddz, B, ws, st, need_encoder,
                 gside, dz_nslab, dz_ss));
-  if (need_encoder) {
+  if (need_encoder && c.encoder == 1) {
+    // frozen backbone: the gradient stops at its feature map; only the spatial-embedding kernels are trained.  Backward
+    // of the Dropout = the same mask on the gradient, then dK[h,w,c,f] = sum_b feat[b,h,w,c] denc[b,c,f].
+    const int HW = c.fh * c.fw, F8 = c.fc * SLE_FEATURES;
+    WSF(ws, st, denc, (size_t)B * c.enc_dim, "denc_%c", tag);
+    const float* douts[MAX_CAM]; const float* kers[MAX_CAM]; const void* feats[MAX_CAM]; float* dker[MAX_CAM];
+    for (int ci = 0; ci < c.ncam; ++ci) {
+      if (drop && c.enc_drop > 0.f) {
+        unsigned k[2];
+        DRV(serl_prng_fold_in(drop[0], drop[1], (unsigned)ci, k));
+        DRV(serl_dropout(denc + (size_t)ci * F8, c.enc_dim, B, F8, k[0], k[1], 1.0f - c.enc_drop, f.row0, f.total_rows, st));
+      }
+      douts[ci] = denc + (size_t)ci * F8;
+      kers[ci] = store.at(eo.sle[ci]);
+      feats[ci] = f.bb[0][ci] + (size_t)lo * HW * c.fc;
+      dker[ci] = grads.at(eo.sle[ci]);
+    }
+    hipStream_t sw = st;
+    if (gside) DRV(gside->fork(&sw));
+    DRV(serl_sle_bwd(c.ncam, douts, c.enc_dim, kers, feats, nullptr, dker, B, HW, c.fc, SLE_FEATURES, 0, sw));
+  } else if (need_encoder) {
     const size_t img_bytes = (size_t)c.H * c.W * 3 * c.stack;
     const unsigned char* imgs[MAX_CAM];
     for (int ci = 0; ci < c.ncam; ++ci) imgs[ci] = f.aug[0][ci] + lo * img_bytes;
@@ -820,8 +882,8 @@ extern "C" int serl_learner_create(const serl_learner_config* pc, const long lon
   SERL_CHECK_ARG(pc && critic_offsets && actor_offsets && out, "learner_create: null pointer");
   SERL_CHECK_ARG(pc->num_hidden >= 1 && pc->num_hidden <= MAX_HID, "learner_create: 1..%d hidden layers", MAX_HID);
   SERL_CHECK_ARG(pc->num_qs >= 1 && pc->action_dim >= 1, "learner_create: bad ensemble / action size");
-  SERL_CHECK_ARG(!pc->pixel || (pc->num_cameras >= 1 && pc->num_cameras <= MAX_CAM && pc->num_conv >= 1 &&
-                                pc->num_conv <= MAX_CONV),
+  SERL_CHECK_ARG(!pc->pixel || (pc->num_cameras >= 1 && pc->num_cameras <= MAX_CAM &&
+                                (pc->encoder == 1 || (pc->encoder == 0 && pc->num_conv >= 1 && pc->num_conv <= MAX_CONV))),
                  "learner_create: 1..%d cameras, 1..%d conv layers", MAX_CAM, MAX_CONV);
   serl_learner* h = new serl_learner();
   Cfg& c = h->cfg;
@@ -833,7 +895,20 @@ extern "C" int serl_learner_create(const serl_learner_config* pc, const long lon
   c.stack = pc->stack; c.state_dim = pc->state_dim; c.latent_dim = pc->latent_dim; c.nl = pc->num_conv;
   c.discount = pc->discount; c.tau = pc->tau; c.target_entropy = pc->target_entropy;
   c.actor_lr = pc->actor_lr; c.critic_lr = pc->critic_lr; c.temp_lr = pc->temp_lr;
-  if (c.pixel) {
+  c.encoder = pc->encoder; c.fh = pc->feat_h; c.fw = pc->feat_w; c.fc = pc->feat_c; c.enc_drop = pc->encoder_dropout;
+  if (c.pixel && c.encoder == 1) {
+    int fh, fw, fc;
+    const bool ok = c.stack == 1 && serl_mbv3_feature_shape(c.H, c.W, &fh, &fw, &fc) == SERL_OK && fh == c.fh && fw == c.fw &&
+                    fc == c.fc && c.enc_drop >= 0.f && c.enc_drop < 1.f;
+    if (!ok) {
+      delete h;
+      SERL_CHECK_ARG(false, "learner_create: mobilenet encoder needs (H, W, 3, 1) images of at least 32x32 and the backbone's feature shape");
+    }
+    c.nl = 0;
+    for (int ci = 0; ci < c.ncam; ++ci) c.aug_rank[ci] = pc->aug_rank[ci];
+    c.enc_dim = c.ncam * c.fc * SLE_FEATURES;
+    c.latent = TRUNK_DIM + c.latent_dim;
+  } else if (c.pixel) {
     int hh = c.H, ww = c.W, cc = 3 * c.stack;
     for (int li = 0; li < c.nl; ++li) {
       const int f = pc->cnn_features[li], k = pc->cnn_filters[li], s = pc->cnn_strides[li];
@@ -908,6 +983,13 @@ extern "C" int serl_learner_create(const serl_learner_config* pc, const long lon
   return SERL_OK;
 }
 
+// frozen MobileNetV3 parameters (serl_mbv3_param_floats floats, device) shared by every network of the learner
+extern "C" int serl_learner_set_backbone(serl_learner* h, const float* params) {
+  SERL_CHECK_ARG(h && params, "learner_set_backbone: null pointer");
+  h->backbone = params;
+  return SERL_OK;
+}
+
 extern "C" int serl_learner_destroy(serl_learner* h) {
   if (!h) return SERL_OK;
   (void)hipDeviceSynchronize();
@@ -962,21 +1044,23 @@ extern "C" int serl_learner_update(serl_learner* h, const serl_agent_buffers* ag
       rng[0] = b[0]; rng[1] = b[1];
     }
   }
-  std::vector<uint32_t> step_keys((size_t)utd * 4);
+  std::vector<uint32_t> step_keys((size_t)utd * 8);   // per step: next-action noise, subsample, target dropout, critic dropout
   for (int i = 0; i < utd; ++i) {
     uint32_t k[2], r[2];
-    split2(rng, k, r); step_keys[4 * i] = k[0]; step_keys[4 * i + 1] = k[1];         // next-action noise
-    split2(r, k, rng); step_keys[4 * i + 2] = k[0]; step_keys[4 * i + 3] = k[1];     // subsample_ensemble
-    split2(rng, k, r);                                                               // target dropout key (consumed, unused)
-    split2(r, k, rng);                                                               // critic dropout key
+    uint32_t* sk = &step_keys[8 * i];
+    split2(rng, k, r); sk[0] = k[0]; sk[1] = k[1];         // next-action noise
+    split2(r, k, rng); sk[2] = k[0]; sk[3] = k[1];         // subsample_ensemble
+    split2(rng, k, r); sk[4] = k[0]; sk[5] = k[1];         // dropout key of the target apply (only the MobileNet encoder has a Dropout)
+    split2(r, k, rng); sk[6] = k[0]; sk[7] = k[1];         // dropout key of the critic apply
   }
-  uint32_t key_pi[2], tmp[2], r2[2];
-  split2(rng, key_pi, r2);       // actor step (sac_learner.py:121-122): policy sample key
-  split2(r2, tmp, rng);          // ... and its critic dropout key
+  uint32_t key_pi[2], key_drop_pi[2], r2[2];
+  split2(rng, key_pi, r2);            // actor step (sac_learner.py:121-122): policy sample key
+  split2(r2, key_drop_pi, rng);       // ... and its critic dropout key
   rng_out[0] = rng[0]; rng_out[1] = rng[1];
 
   // ---- inputs
   Feats f;
+  f.row0 = rank * B; f.total_rows = Bg;
   f.obs = bt->obs; f.next_obs = bt->next_obs; f.state = bt->state; f.next_state = bt->next_state;
   SERL_CHECK_ARG(bt->actions && bt->rewards && bt->masks, "learner_update: actions / rewards / masks missing");
   if (!c.pixel) SERL_CHECK_ARG(f.obs && f.next_obs, "learner_update: observations missing");
@@ -1021,6 +1105,25 @@ extern "C" int serl_learner_update(serl_learner* h, const serl_agent_buffers* ag
         }
       }
     }
+    if (c.encoder == 1) {
+      // The backbone is frozen and the same in the actor, the critic and the target critic (a module attribute, not a
+      // parameter: two_mobilenet_encoder.py:12,31), so its features of the augmented obs / next_obs images are computed
+      // ONCE per call for all B*U rows; the three passes of every critic step only pool them (trainable SLE kernels).
+      SERL_CHECK_ARG(h->backbone, "learner_update: serl_learner_set_backbone has not been called");
+      const int chunk = std::min(n, 256);
+      const long long wsb = serl_mbv3_workspace_bytes(chunk, c.H, c.W);
+      WSF(ws, st, bbws, (size_t)wsb / 4, "bb_ws");
+      const size_t fsz = (size_t)c.fh * c.fw * c.fc, img1 = (size_t)c.H * c.W * 3;
+      for (int side = 0; side < 2; ++side)
+        for (int ci = 0; ci < c.ncam; ++ci) {
+          WSF(ws, st, bb, (size_t)n * fsz, "bb_%d_%d", side, ci);
+          f.bb[side][ci] = bb;
+          for (int r0 = 0; r0 < n; r0 += chunk) {
+            const int m = std::min(chunk, n - r0);
+            DRV(serl_mbv3_forward(h->backbone, f.aug[side][ci] + r0 * img1, 1, m, c.H, c.W, bbws, wsb, bb + r0 * fsz, st));
+          }
+        }
+    }
   }
 
   WSF(ws, st, zA, (size_t)B * ldz, "zA");
@@ -1042,7 +1145,7 @@ extern "C" int serl_learner_update(serl_learner* h, const serl_agent_buffers* ag
   auto enqueue_actor = [&](int j) -> int {
     FPass p{'A', actor, &ao.e, 1, zA, sta};
     DRV(features(h, &p, 1, f, j * B, B, ws, sta, 0, nullptr, j == 0));   // S-format weight copies made once (j == 0)
-    DRV(policy_fwd(h, 'A', actor, ao, zA, ldz, B, ws, sta, &step_keys[4 * j], rank * B, Bg,
+    DRV(policy_fwd(h, 'A', actor, ao, zA, ldz, B, ws, sta, &step_keys[8 * j], rank * B, Bg,
                    zT_all + ((size_t)j * B * ldz + c.latent), ldz, false, false, c.backup_entropy != 0,
                    nlogp_all + (size_t)j * B, nullptr));
     if (sta != st) DRV_HIP(hipEventRecord(h->adone[j], sta));
@@ -1065,11 +1168,11 @@ extern "C" int serl_learner_update(serl_learner* h, const serl_agent_buffers* ag
     // ---- critic step (sac_learner.py:160-219)
     int m0, mstride, emin;
     Store tstore;
-    DRV(target_members(h, &step_keys[4 * i + 2], target, ws, st, &m0, &mstride, &emin, &tstore));
+    DRV(target_members(h, &step_keys[8 * i + 2], target, ws, st, &m0, &mstride, &emin, &tstore));
     float* zT = zT_all + (size_t)i * B * ldz;
     {
       // target chain on the main stream, critic chain on a side stream, next action from the actor stream
-      FPass ps[2] = {{'T', target, &co.e, 1, zT, st}, {'C', critic, &co.e, 0, zC, s1}};
+      FPass ps[2] = {{'T', target, &co.e, 1, zT, st, &step_keys[8 * i + 4]}, {'C', critic, &co.e, 0, zC, s1, &step_keys[8 * i + 6]}};
       DRV(features(h, ps, 2, f, lo, B, ws, st, 'C', h->fork_ev, true));
     }
     DRV(phase(h, "features_fwd", st));
@@ -1092,7 +1195,7 @@ extern "C" int serl_learner_update(serl_learner* h, const serl_agent_buffers* ag
     float* dinp = nullptr; int nslab = 1; long long ss = 0;
     DRV(ensemble_bwd(h, 'C', critic, co, &cgr, dq, zC, ldz, B, ws, st, &h->gside, c.pixel ? 2 : 0, &dinp, &nslab, &ss));
     DRV(phase(h, "ensemble_bwd", st));
-    DRV(features_bwd(h, 'C', critic, co.e, cgr, f, lo, B, ws, st, dinp, ldz, true, &h->gside, nslab, ss));
+    DRV(features_bwd(h, 'C', critic, co.e, cgr, f, lo, B, ws, st, dinp, ldz, true, &h->gside, nslab, ss, &step_keys[8 * i + 6]));
     DRV(h->gside.join());
     DRV(phase(h, "features_bwd", st));
     if (world > 1) DRV(allreduce(allreduce_ctx, 0));   // data parallel: one all-reduce(sum) of the flat gradient per step
@@ -1109,7 +1212,7 @@ extern "C" int serl_learner_update(serl_learner* h, const serl_agent_buffers* ag
   // the actor's own pass over obs ran ahead; only the critic pass with the post-UTD critic parameters is left here
   if (sta != st) DRV_HIP(hipStreamWaitEvent(st, h->aobs, 0));
   {
-    FPass p{'C', critic, &co.e, 0, zP, st};
+    FPass p{'C', critic, &co.e, 0, zP, st, key_drop_pi};
     DRV(features(h, &p, 1, f, lo, B, ws, st, 0, nullptr, true));
   }
   float* q;
@@ -1156,7 +1259,21 @@ extern "C" int serl_learner_act(serl_learner* h, const float* actor_params, cons
   Workspace& ws = h->ws_act;
   const Store actor{(float*)actor_params};
   WSF(ws, st, z, (size_t)c.ldz, "zA");
-  if (c.pixel) {
+  if (c.pixel && c.encoder == 1) {
+    SERL_CHECK_ARG(images && h->backbone, "learner_act: images or backbone missing");
+    const long long wsb = serl_mbv3_workspace_bytes(1, c.H, c.W);
+    WSF(ws, st, bbws, (size_t)wsb / 4, "bb_ws");
+    Feats f;
+    f.row0 = 0; f.total_rows = 1;
+    for (int ci = 0; ci < c.ncam; ++ci) {
+      WSF(ws, st, bb, (size_t)c.fh * c.fw * c.fc, "bb_0_%d", ci);
+      DRV(serl_mbv3_forward(h->backbone, images[ci], 1, 1, c.H, c.W, bbws, wsb, bb, st));
+      f.bb[0][ci] = bb;
+    }
+    FPass p{'A', actor, &h->ao.e, 0, z, st};       // training=False: no Dropout (agent.py:12-22)
+    DRV(mobilenet_sle_fwd(h, &p, 1, f, 0, 1, ws, st));
+    DRV(trunk_fwd(h, 'A', actor, h->ao.e, state_or_obs, z, c.ldz, 1, ws, st, false));
+  } else if (c.pixel) {
     SERL_CHECK_ARG(images, "learner_act: images missing");
     Pass p; p.tag = 'A'; p.store = actor; p.eo = &h->ao.e;
     for (int ci = 0; ci < c.ncam; ++ci) p.imgs[ci] = images[ci];

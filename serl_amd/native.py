@@ -24,7 +24,8 @@ class LearnerConfig(C.Structure):
                 ("latent_dim", C.c_int), ("num_conv", C.c_int), ("cnn_features", C.c_int * 8),
                 ("cnn_filters", C.c_int * 8), ("cnn_strides", C.c_int * 8), ("aug_rank", C.c_int * 4),
                 ("discount", C.c_float), ("tau", C.c_float), ("target_entropy", C.c_float), ("actor_lr", C.c_float),
-                ("critic_lr", C.c_float), ("temp_lr", C.c_float)]
+                ("critic_lr", C.c_float), ("temp_lr", C.c_float), ("encoder", C.c_int), ("feat_h", C.c_int),
+                ("feat_w", C.c_int), ("feat_c", C.c_int), ("encoder_dropout", C.c_float)]
 
 
 class AgentBuffers(C.Structure):
@@ -75,6 +76,8 @@ class NativeLearner:
             lc.state_dim, lc.latent_dim, lc.num_conv = cfg.state_dim, cfg.latent_dim, len(cfg.cnn_features)
             for i, (f, k, s) in enumerate(zip(cfg.cnn_features, cfg.cnn_filters, cfg.cnn_strides)):
                 lc.cnn_features[i], lc.cnn_filters[i], lc.cnn_strides[i] = int(f), int(k), int(s)
+            lc.encoder = {"d4pg": 0, "mobilenet": 1}[cfg.encoder]
+            lc.feat_h, lc.feat_w, lc.feat_c, lc.encoder_dropout = cfg.feat_h, cfg.feat_w, cfg.feat_c, cfg.encoder_dropout
             for ci, cam in enumerate(cams):           # augmentation keys are split in the caller's key order
                 lc.aug_rank[ci] = cfg.pixel_keys.index(cam)
         lc.discount, lc.tau, lc.target_entropy = float(discount), float(tau), float(target_entropy)
@@ -94,6 +97,11 @@ class NativeLearner:
                 _lib.load().serl_learner_destroy(h)
             except Exception:       # noqa: BLE001  interpreter shutdown
                 pass
+
+    def set_backbone(self, backbone):
+        """The frozen MobileNetV3 feature extractor (serl_amd.networks.mobilenet.Backbone) of a mobilenet-encoder learner."""
+        self._backbone = backbone          # keeps the device buffer alive
+        _lib.call("serl_learner_set_backbone", self._h, backbone.flat.data_ptr())
 
     # ------------------------------------------------------------------ update
     def update(self, buffers: AgentBuffers, batch: UpdateBatch, utd_ratio, rng, info_out, stream, dist=None,

@@ -41,6 +41,12 @@ class NetConfig:
     H: int = 0; W: int = 0; stack: int = 0
     cnn_features: Tuple[int, ...] = (); cnn_filters: Tuple[int, ...] = (); cnn_strides: Tuple[int, ...] = ()
     latent_dim: int = 50
+    # image encoder: "d4pg" (TwoD4PGEncoder: trainable conv stack) or "mobilenet" (TwoMobileNetEncoder: frozen
+    # MobileNetV3-Large backbone whose (feat_h, feat_w, feat_c) feature map feeds the trainable spatial embeddings,
+    # followed by Dropout(encoder_dropout) in training mode; two_mobilenet_encoder.py:10-45)
+    encoder: str = "d4pg"
+    feat_h: int = 0; feat_w: int = 0; feat_c: int = 0
+    encoder_dropout: float = 0.1
 
     @property
     def pixel(self):
@@ -53,6 +59,8 @@ class NetConfig:
 
     def conv_layers(self):
         out = []
+        if self.encoder != "d4pg":
+            return out
         h, w, c = self.H, self.W, 3 * self.stack
         for f, k, s in zip(self.cnn_features, self.cnn_filters, self.cnn_strides):
             oh, ow = (h - k) // s + 1, (w - k) // s + 1
@@ -61,9 +69,16 @@ class NetConfig:
         return out
 
     @property
+    def sle_shape(self):
+        """(H, W, C) of the feature map the spatial embeddings pool."""
+        if self.encoder == "d4pg":
+            last = self.conv_layers()[-1]
+            return last.OH, last.OW, last.F
+        return self.feat_h, self.feat_w, self.feat_c
+
+    @property
     def enc_dim(self):
-        ls = self.conv_layers()
-        return len(self.pixel_keys) * ls[-1].F * SLE_FEATURES
+        return len(self.pixel_keys) * self.sle_shape[2] * SLE_FEATURES
 
     @property
     def latent(self):
@@ -79,9 +94,9 @@ def _add_encoder_and_trunk(lay: Layout, cfg: NetConfig):
             name = f"Conv_{ci * nl + li}"
             lay.add(("image_encoder", name, "kernel"), (L.K, L.K, L.C, L.F))
             lay.add(("image_encoder", name, "bias"), (L.F,))
-    last = layers[-1]
+    fh, fw, fc = cfg.sle_shape
     for ci in range(len(cfg.cams)):
-        lay.add(("image_encoder", f"SpatialLearnedEmbeddings_{ci}", "kernel"), (last.OH, last.OW, last.F, SLE_FEATURES))
+        lay.add(("image_encoder", f"SpatialLearnedEmbeddings_{ci}", "kernel"), (fh, fw, fc, SLE_FEATURES))
     lay.add(("Dense_0", "kernel"), (cfg.enc_dim, TRUNK_DIM)); lay.add(("Dense_0", "bias"), (TRUNK_DIM,))
     lay.add(("LayerNorm_0", "scale"), (TRUNK_DIM,)); lay.add(("LayerNorm_0", "bias"), (TRUNK_DIM,))
     lay.add(("Dense_1", "kernel"), (cfg.state_dim, cfg.latent_dim)); lay.add(("Dense_1", "bias"), (cfg.latent_dim,))

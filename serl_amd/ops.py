@@ -249,3 +249,7 @@ def take_rows(src, nrows, row_bytes, indx, out, n, stream):
 
 def crop_offsets(key, n, row_offset, n_total, pad, out, stream):
     call("serl_crop_offsets", int(key[0]), int(key[1]), n, row_offset, n_total, pad, out, stream)
+
+
+def dropout(x, ld, rows, cols, key, keep_prob, row_offset, total_rows, stream):
+    call("serl_dropout", x, ld, rows, cols, int(key[0]), int(key[1]), float(keep_prob), row_offset, total_rows, stream)

@@ -32,3 +32,9 @@ def choice_no_replace(key, n: int, m: int) -> np.ndarray:
     out = np.empty(m, dtype=np.int32)
     _lib.call("serl_prng_choice", int(key[0]), int(key[1]), n, m, out.ctypes.data_as(C.c_void_p))
     return out
+
+
+def fold_in(key, data: int) -> np.ndarray:
+    out = np.empty(2, dtype=np.uint32)
+    _lib.call("serl_prng_fold_in", int(key[0]), int(key[1]), int(data) & 0xFFFFFFFF, out.ctypes.data_as(C.c_void_p))
+    return out

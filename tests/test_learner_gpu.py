@@ -610,3 +610,49 @@ def test_free_running_drift(dev, shape, prec):
         for k, v in r["product_vs_f64"].items():
             assert v <= max(bound, 4.0 * r["f32_oracle_vs_f64"][k]), \
                 f"call {r['call']} {k}: product drift {v:.3e} > {bound:.1e} (fp32 oracle {r['f32_oracle_vs_f64'][k]:.3e})"
+
+
+@pytest.mark.parametrize("utd", [1, 2])
+def test_drq_mobilenet_encoder_matches_oracle(dev, utd, prec):
+    """BASELINE config 4's learner: DrQ-RLPD with encoder="mobilenet" (TwoMobileNetEncoder: ImageNet normalisation,
+    frozen MobileNetV3-Large backbone, trainable SpatialLearnedEmbeddings, Dropout(0.1) in the training=True applies of
+    the critic and target critic; two_mobilenet_encoder.py:19-34, sac_learner.py:177-206,129-134).  Synthetic backbone
+    weights (pretrained ones are not available offline: backbone parity unpinned), dropout mask stream build-defined
+    (oracle/learner.py encoder_dropout).  Two update() calls vs the oracle, augmented images bit-exact."""
+    from oracle import learner as ol
+    from serl_amd.agents import DrQLearner
+    keys = ("wrist_1", "wrist_2")
+    H = W = 64; S = 1; B, U = 4, utd
+    obs_space, act_space = pixel_spaces(keys, H, W, S, 19, 7)
+    agent = DrQLearner.create(11, obs_space, act_space, pixel_keys=keys, encoder="mobilenet", latent_dim=64, num_qs=10,
+                              num_min_qs=2, critic_layer_norm=True, backup_entropy=False, init_temperature=0.1)
+    assert agent._cfg.enc_dim == 2 * 960 * 8 and agent._cfg.sle_shape == (2, 2, 960)
+    assert set(agent.critic.params["image_encoder"]) == {"SpatialLearnedEmbeddings_0", "SpatialLearnedEmbeddings_1"}
+    rng = np.random.default_rng(7)
+    info_tol = 1e-3 if (prec == "highest" or U == 1) else 5e-3
+    for it in range(2):
+        ostate, ocfg = agent_to_oracle(agent)          # per-call parity from the product's own state
+        batch = make_pixel_batch(rng, B * U, keys, H, W, S, 19, 7, packed=True)
+        collect, c64 = [], []
+        if U == 1:
+            ol.drq_update(ostate, ocfg, batch, U, dtype=torch.float64, collect=c64)
+        ostate, oinfo = ol.drq_update(ostate, ocfg, batch, U, collect=collect)
+        agent, info = agent.update(batch, U, pixel_keys=keys)
+        ws = agent._ws(B)
+        for side, okey in (("obs", "observations"), ("next", "next_observations")):
+            for cam in keys:
+                got = ws.tensor(f"aug_{side}_{cam}", (B * U, H, W, 3 * S), torch.uint8).cpu().numpy()
+                assert np.array_equal(got.reshape(B * U, H, W, 3, S), collect[0][okey][cam]), f"aug {side} {cam}"
+        assert_info_close(info, oinfo, rtol=info_tol)
+        assert np.array_equal(agent.rng, ostate["rng"])
+        if U == 1:
+            _check_grads(agent, "critic_grads", c64[-2]["grads"], None, prec, 3e-4, noise_ref=collect[-2]["grads"])
+            _check_grads(agent, "actor_grads", c64[-1]["grads"], None, prec, 5e-4, noise_ref=collect[-1]["grads"])
+    _check_params(agent, ostate, 3e-4, U)
+    ob = {k: rng.integers(0, 256, size=(H, W, 3, S), dtype=np.uint8) for k in keys}
+    ob["state"] = rng.standard_normal(19).astype(np.float32)
+    osync, ocfg = agent_to_oracle(agent)
+    a, agent2 = agent.sample_actions(ob)
+    oa, osync2 = ol.sample_actions(osync, ocfg, ob)
+    assert np.allclose(a, oa, atol=5e-4) and np.array_equal(agent2.rng, osync2["rng"])
+    assert np.allclose(agent.eval_actions(ob), ol.eval_actions(osync, ocfg, ob), atol=5e-4)
