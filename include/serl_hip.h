@@ -107,13 +107,13 @@ int serl_mbv3_forward(const float* params, const void* images, int in_u8, int n,
 /* ---- batched / segmented dense GEMM: nn.Dense of serl/networks/mlp.py:21-25, pixel_multiplexer.py:34,39, the
  * nn.vmap ensemble of serl/networks/ensemble.py:14-22 (nbatch = members) and their backward products.
  * C[z][m][n] = sum_k A[z][m][k] B[z][k][n] (+bias[z][n]) (act) ; element strides as named; k = seg*seglen + r;
- * relu = activation code of the epilogue: 0 none, 1 ReLU, 2 hard-swish, 3 hard-sigmoid. */
+ * relu = activation code of the epilogue: 0 none, 1 ReLU, 2 hard-swish, 3 hard-sigmoid, 4 sigmoid. */
 int serl_gemm(const float* a, const float* b, float* c, const float* bias, int nbatch, int M, int N, int K, int seglen,
               long long a_zs, long long a_ss, long long a_ms, long long a_ks, long long b_zs, long long b_ss,
               long long b_ks, long long b_ns, long long c_zs, long long c_ms, long long bias_zs, int nsplit,
               long long c_split_stride, int relu, int accumulate, int a_kcontig, int b_ncontig, void* stream);
 
-/* ---- bias + LayerNorm (flax eps 1e-6) + activation (0 none, 1 relu, 2 tanh): serl/networks/mlp.py:27-34,
+/* ---- bias + LayerNorm (flax eps 1e-6) + activation (0 none, 1 relu, 2 tanh, 3 leaky_relu slope 0.01): serl/networks/mlp.py:27-34,
  * pixel_multiplexer.py:35-36,42-43; sums `nslab` split-K partials first. Rows are grouped per ensemble member. */
 int serl_ln_act_fwd(const float* pre, int nslab, long long pre_slab_stride, int ldpre, const float* bias,
                     const float* gamma, const float* beta, long long param_group_stride, float* y, int ldy,
@@ -158,6 +158,11 @@ int serl_fill(float* p, float v, long long n, void* stream);
  * keep = jax.random.bernoulli(key, keep_prob, (total_rows, cols))[row_offset + r][c]. */
 int serl_dropout(float* x, int ld, int rows, int cols, unsigned k0, unsigned k1, float keep_prob, int row_offset,
                  int total_rows, void* stream);
+
+/* VICE reward, serl/agents/vice/vice_learner.py:262-274,301: sigmoids[c][i] = sigmoid(logits[c][i]) (optional outputs),
+ * mean_out[i] = mean over the ncam <= 4 cameras, rewards[i] = log(mean / (1 - mean)); argument tables are host arrays. */
+int serl_vice_reward(int ncam, const float* const* logits, float* const* sigmoids, float* mean_out, float* rewards, int n,
+                     void* stream);
 
 /* ---- tanh-Gaussian policy head, serl/distributions/tanh_normal.py:29-48 + TFP MultivariateNormalDiag/Tanh;
  * eps = jax.random.normal(key, (total_rows, A))[row_offset : row_offset + B] (threefry2x32, XLA erf_inv). */
@@ -251,9 +256,15 @@ typedef struct {
   const float *obs, *next_obs;       /* state-based */
   const float *state, *next_state;   /* pixel-based */
   serl_pixel_source pixels[4];       /* cameras in sorted-key order */
+  int features_hook;                 /* != 0: call the hook with which = 3 once the features of all rows are enqueued */
+  int use_sac_rng; unsigned sac_rng[2];   /* != 0: the SAC update's split chain starts from sac_rng instead of the key the
+                                        augmentation left (VICELearner.update: vice_reward advances it, :255-260,275) */
 } serl_update_batch;
 /* data-parallel hook: sum buffer `which` over the ranks (0 critic_grads, 1 actor_grads, 2 the first 4 info floats --
- * serl_learner_update passes info_out for those), behind the work enqueued on the update's stream; returns 0 on success */
+ * serl_learner_update passes info_out for those), behind the work enqueued on the update's stream; returns 0 on success.
+ * which = 3 ("features ready", only when serl_update_batch.features_hook != 0): the augmented images and, for the
+ * MobileNet encoder, the backbone features of all rows are enqueued; the hook may enqueue work on the update's stream
+ * that overwrites the batch's rewards before the first critic step reads them (VICELearner.update, vice_learner.py:300-308) */
 typedef int (*serl_allreduce_fn)(void* ctx, int which);
 /* critic_offsets / actor_offsets: offsets in floats of every leaf of the flat stores in the layout order of
  * serl_amd/networks/spec.py (encoder + trunk leaves first for pixel learners), followed by the store's total size */
@@ -275,6 +286,9 @@ int serl_learner_act(serl_learner* h, const float* actor_params, const unsigned 
                      void* stream);
 /* test / tooling access: copy a named workspace buffer of the update at minibatch size B ("aug_<0 obs|1 next>_<cam>") */
 int serl_learner_read_buffer(serl_learner* h, int B, const char* name, void* dst, long long nbytes, void* stream);
+/* device address and size of a named workspace buffer ("bb_<side>_<cam>": the frozen backbone's features of the augmented
+ * images, (n, fh, fw, fc) fp32) -- what a `features ready` hook (serl_allreduce_fn, which = 3) reads */
+int serl_learner_buffer_ptr(serl_learner* h, int B, const char* name, void** ptr, long long* nbytes);
 long long serl_learner_workspace_bytes(serl_learner* h);
 /* bench.py instrumentation: HIP events around every conv launch (on its launch stream) / between the phases of a step */
 int serl_learner_set_timing(serl_learner* h, int conv_events, int phase_events);

@@ -77,6 +77,7 @@ _SIGS = {
     "serl_learner_update": [c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i],
     "serl_learner_act": [c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p],
     "serl_learner_read_buffer": [c_p, c_i, C.c_char_p, c_p, c_ll, c_p],
+    "serl_learner_buffer_ptr": [c_p, c_i, C.c_char_p, c_p, c_p],
     "serl_learner_workspace_bytes": [c_p],
     "serl_learner_set_timing": [c_p, c_i, c_i],
     "serl_learner_timing_count": [c_p],
@@ -88,6 +89,7 @@ _SIGS = {
     "serl_prng_bits": [c_u, c_u, c_i, c_p],
     "serl_prng_choice": [c_u, c_u, c_i, c_i, c_p],
     "serl_prng_fold_in": [c_u, c_u, c_u, c_p],
+    "serl_vice_reward": [c_i, PP, PP, c_p, c_p, c_i, c_p],
     "serl_dropout": [c_p, c_i, c_i, c_i, c_u, c_u, c_f, c_i, c_i, c_p],
 }
 _RESTYPE = {"serl_conv2d_wgrad_workspace_bytes": c_ll, "serl_convs_weight_bytes": c_ll,

@@ -47,9 +47,10 @@ class UpdateInfo(Mapping):
     first access (indexing, iteration over items, comparison, dict(info)) copies the 8 floats to the host."""
     KEYS = ("actor_loss", "entropy", "critic_loss", "q", "temperature", "temperature_loss")
 
-    def __init__(self, dev_scalars, global_batch, num_qs, keys=None):
+    def __init__(self, dev_scalars, global_batch, num_qs, keys=None, extra=None):
         self._dev, self._bg, self._e, self._host = dev_scalars, global_batch, num_qs, None
         self._keys = tuple(keys) if keys is not None else self.KEYS
+        self._extra = extra or {}        # key -> (1-element device tensor, scale): e.g. VICELearner's "vice_rews"
 
     def _materialize(self):
         if self._host is None:
@@ -60,8 +61,10 @@ class UpdateInfo(Mapping):
                 "critic_loss": float(h[0]) / (e * bg), "q": float(h[1]) / (e * bg),
                 "temperature": float(h[4]), "temperature_loss": float(h[5]),
             }
+            for k, (t, scale) in self._extra.items():
+                full[k] = float(t.cpu().numpy().reshape(-1)[0]) * scale
             self._host = {k: full[k] for k in self._keys}
-            self._dev = None
+            self._dev, self._extra = None, {}
         return self._host
 
     def __getitem__(self, k):
@@ -166,7 +169,7 @@ class SACLearner(Agent):
         ub.obs, ub.next_obs = keep[0].data_ptr(), keep[1].data_ptr()
         return self._run_update(batch, ub, n, utd_ratio, self.actor.clone(), self.rng, keep)
 
-    def _run_update(self, batch, ub: UpdateBatch, n, utd_ratio, actor, rng, keep):
+    def _run_update(self, batch, ub: UpdateBatch, n, utd_ratio, actor, rng, keep, features_hook=None, extra_info=None):
         """Clone the state (functional semantics: `self` stays valid and unchanged), hand the pointers to the driver."""
         cfg = self._cfg
         dev = self.actor.store.flat.device
@@ -190,11 +193,11 @@ class SACLearner(Agent):
         ab.actor_step, ab.critic_step, ab.temp_step = actor.step, critic.step, temp.step
         with torch.cuda.device(dev):
             new_rng = self._native.update(ab, ub, utd_ratio, rng, info.data_ptr(), ops.current_stream(), dist=dist,
-                                          reduce_tensors=(cgr.flat, agr.flat, info[:4]))
+                                          reduce_tensors=(cgr.flat, agr.flat, info[:4]), features_hook=features_hook)
         critic.step += utd_ratio
         actor.step += 1
         if self._HAS_TEMP:
             temp.step += 1
         del keep, actions, rewards, masks      # (stream-ordered frees: the caching allocator reuses them on this stream)
         new_agent = self.replace(actor=actor, critic=critic, target_critic=target, temp=temp, rng=new_rng)
-        return new_agent, UpdateInfo(info, n // utd_ratio * world, cfg.num_qs, self._INFO_KEYS)
+        return new_agent, UpdateInfo(info, n // utd_ratio * world, cfg.num_qs, self._INFO_KEYS, extra_info)

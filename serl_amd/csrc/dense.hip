@@ -78,7 +78,8 @@ struct GemmP {
     v += oc.bias + aux;
     if (g.relu == 1) v = fmaxf(v, 0.f);                                              // activation code: 1 ReLU,
     else if (g.relu == 2) v = v * fminf(fmaxf(v + 3.f, 0.f), 6.f) * (1.f / 6.f);     // 2 hard-swish,
-    else if (g.relu == 3) v = fminf(fmaxf(v + 3.f, 0.f), 6.f) * (1.f / 6.f);         // 3 hard-sigmoid (MobileNetV3)
+    else if (g.relu == 3) v = fminf(fmaxf(v + 3.f, 0.f), 6.f) * (1.f / 6.f);         // 3 hard-sigmoid (MobileNetV3),
+    else if (g.relu == 4) v = 1.f / (1.f + expf(-v));                                // 4 sigmoid (reward classifiers)
     c.c[split * g.c_ss + o.off + n] = v;
   }
 };

@@ -1044,6 +1044,7 @@ extern "C" int serl_learner_update(serl_learner* h, const serl_agent_buffers* ag
       rng[0] = b[0]; rng[1] = b[1];
     }
   }
+  if (bt->use_sac_rng) { rng[0] = bt->sac_rng[0]; rng[1] = bt->sac_rng[1]; }
   std::vector<uint32_t> step_keys((size_t)utd * 8);   // per step: next-action noise, subsample, target dropout, critic dropout
   for (int i = 0; i < utd; ++i) {
     uint32_t k[2], r[2];
@@ -1126,6 +1127,10 @@ extern "C" int serl_learner_update(serl_learner* h, const serl_agent_buffers* ag
     }
   }
 
+  if (bt->features_hook) {
+    SERL_CHECK_ARG(allreduce, "learner_update: features_hook without a hook function");
+    DRV(allreduce(allreduce_ctx, 3));
+  }
   WSF(ws, st, zA, (size_t)B * ldz, "zA");
   WSF(ws, st, zC, (size_t)B * ldz, "zC");
   WSF(ws, st, zP, (size_t)B * ldz, "zC_pi");                    // critic input of the actor step
@@ -1302,6 +1307,17 @@ extern "C" int serl_learner_read_buffer(serl_learner* h, int B, const char* name
   SERL_CHECK_ARG(it != w->second.m.end(), "learner_read_buffer: no buffer named %s", name);
   SERL_CHECK_ARG((size_t)nbytes <= it->second.bytes, "learner_read_buffer: %s holds %zu bytes", name, it->second.bytes);
   DRV_HIP(hipMemcpyAsync(dst, it->second.p, (size_t)nbytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return SERL_OK;
+}
+
+extern "C" int serl_learner_buffer_ptr(serl_learner* h, int B, const char* name, void** ptr, long long* nbytes) {
+  SERL_CHECK_ARG(h && name && ptr, "learner_buffer_ptr: bad args");
+  auto w = h->ws_update.find(B);
+  SERL_CHECK_ARG(w != h->ws_update.end(), "learner_buffer_ptr: no update with minibatch size %d has run", B);
+  auto it = w->second.m.find(name);
+  SERL_CHECK_ARG(it != w->second.m.end(), "learner_buffer_ptr: no buffer named %s", name);
+  *ptr = it->second.p;
+  if (nbytes) *nbytes = (long long)it->second.bytes;
   return SERL_OK;
 }
 

@@ -6,6 +6,7 @@
 #define ACT_NONE 0
 #define ACT_RELU 1
 #define ACT_TANH 2
+#define ACT_LEAKY 3   // jax.nn.leaky_relu, negative_slope 0.01 (VICE classifier MLP, vice_learner.py:156)
 #define MAXW 16  // row width <= 64*MAXW = 1024
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -72,6 +73,7 @@ __global__ __launch_bounds__(256) void ln_act_fwd_kernel(const LnFwdArgs a) {
       }
       if (a.act == ACT_RELU) v = fmaxf(v, 0.f);
       else if (a.act == ACT_TANH) v = tanhf(v);
+      else if (a.act == ACT_LEAKY) v = v > 0.f ? v : 0.01f * v;
       a.y[(long long)row * a.ldy + n] = v;
       if (hw) dot += v * hw[n];                 // same lane/column order as rowdot_kernel: bit-identical sums
     }
@@ -169,6 +171,7 @@ __global__ __launch_bounds__(256) void trunk_ln_fwd_kernel(const TrunkLnArgs a) 
       float v = (z[i] - mean) * (mul * gamma[n]) + beta[n];
       if (a.act == ACT_RELU) v = fmaxf(v, 0.f);
       else if (a.act == ACT_TANH) v = tanhf(v);
+      else if (a.act == ACT_LEAKY) v = v > 0.f ? v : 0.01f * v;
       y[(long long)row * a.ldy + n] = v;
     }
   }
@@ -216,6 +219,7 @@ __global__ __launch_bounds__(256) void ln_act_bwd_kernel(const LnBwdArgs a) {
       float dact = 1.f;
       if (a.act == ACT_RELU) dact = yv > 0.f ? 1.f : 0.f;
       else if (a.act == ACT_TANH) dact = 1.f - yv * yv;
+      else if (a.act == ACT_LEAKY) dact = yv > 0.f ? 1.f : 0.01f;
       g = d * dact;
       if (a.use_ln) {
         x = a.xhat[(long long)row * a.N + n];
@@ -293,6 +297,7 @@ __global__ __launch_bounds__(256) void ln_act_bwd_seg_kernel(const LnBwdSegArgs 
       float dact = 1.f;
       if (a.act == ACT_RELU) dact = yv > 0.f ? 1.f : 0.f;
       else if (a.act == ACT_TANH) dact = 1.f - yv * yv;
+      else if (a.act == ACT_LEAKY) dact = yv > 0.f ? 1.f : 0.01f;
       g = d * dact;
       x = a.xhat[sg][(long long)row * N + n];
       const float dxh = g * gamma[n];
@@ -704,5 +709,36 @@ extern "C" int serl_dropout(float* x, int ld, int rows, int cols, unsigned k0, u
   hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)cdivll((long long)rows * cols, 256)), dim3(256), 0, (hipStream_t)stream, x,
                      ld, rows, cols, k0, k1, keep_prob, row_offset, (uint32_t)((long long)total_rows * cols));
   SERL_CHECK_LAUNCH("dropout");
+  return SERL_OK;
+}
+
+// ------------------------------------------------------------------ VICE reward (vice_learner.py:274,301)
+// mean[i] = mean over the cameras of sigmoid(logits[c][i]); rewards[i] = log(mean / (1 - mean)); one thread per sample.
+struct ViceRewArgs { const float* logits[4]; float* sig[4]; int ncam; };
+__global__ void vice_reward_kernel(const ViceRewArgs a, float* mean_out, float* rewards, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float m = 0.f;
+  for (int c = 0; c < a.ncam; ++c) {
+    const float s = 1.f / (1.f + expf(-a.logits[c][i]));
+    if (a.sig[c]) a.sig[c][i] = s;
+    m += s;
+  }
+  m /= (float)a.ncam;
+  if (mean_out) mean_out[i] = m;
+  if (rewards) rewards[i] = logf(m / (1.f - m));
+}
+extern "C" int serl_vice_reward(int ncam, const float* const* logits, float* const* sigmoids, float* mean_out,
+                                float* rewards, int n, void* stream) {
+  SERL_CHECK_ARG(ncam >= 1 && ncam <= 4 && logits && n >= 1, "vice_reward: bad args");
+  ViceRewArgs a;
+  a.ncam = ncam;
+  for (int c = 0; c < ncam; ++c) {
+    SERL_CHECK_ARG(logits[c], "vice_reward: null logits");
+    a.logits[c] = logits[c];
+    a.sig[c] = sigmoids ? sigmoids[c] : nullptr;
+  }
+  hipLaunchKernelGGL(vice_reward_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, a, mean_out, rewards, n);
+  SERL_CHECK_LAUNCH("vice_reward");
   return SERL_OK;
 }

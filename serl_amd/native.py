@@ -42,7 +42,8 @@ class PixelSource(C.Structure):
 class UpdateBatch(C.Structure):
     _fields_ = [("n", C.c_int), ("aug_mode", C.c_int), ("actions", C.c_void_p), ("rewards", C.c_void_p),
                 ("masks", C.c_void_p), ("obs", C.c_void_p), ("next_obs", C.c_void_p), ("state", C.c_void_p),
-                ("next_state", C.c_void_p), ("pixels", PixelSource * 4)]
+                ("next_state", C.c_void_p), ("pixels", PixelSource * 4), ("features_hook", C.c_int),
+                ("use_sac_rng", C.c_int), ("sac_rng", C.c_uint * 2)]
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)
@@ -105,23 +106,29 @@ class NativeLearner:
 
     # ------------------------------------------------------------------ update
     def update(self, buffers: AgentBuffers, batch: UpdateBatch, utd_ratio, rng, info_out, stream, dist=None,
-               reduce_tensors=None):
-        """-> new rng (uint32[2]).  reduce_tensors: (critic_grads, actor_grads, info[:4]) torch tensors for `dist`."""
+               reduce_tensors=None, features_hook=None):
+        """-> new rng (uint32[2]).  reduce_tensors: (critic_grads, actor_grads, info[:4]) torch tensors for `dist`.
+        features_hook(): called once the augmented images / backbone features of all rows are enqueued (VICE rewards)."""
         rin = (C.c_uint * 2)(int(rng[0]), int(rng[1]))
         rout = (C.c_uint * 2)()
         cb, rank, world = C.cast(None, ALLREDUCE_FN), 0, 1
         err = []
-        if dist is not None and dist.world_size > 1:
+        multi = dist is not None and dist.world_size > 1
+        if multi:
             rank, world = dist.rank, dist.world_size
-
-            def allreduce(_ctx, which):
+        batch.features_hook = int(features_hook is not None)
+        if multi or features_hook is not None:
+            def hook(_ctx, which):
                 try:
-                    dist.all_reduce_sum(reduce_tensors[which])
+                    if which == 3:
+                        features_hook()
+                    else:
+                        dist.all_reduce_sum(reduce_tensors[which])
                     return 0
                 except Exception as e:      # noqa: BLE001  surfaced below; a C caller only sees the status
                     err.append(e)
                     return 2
-            cb = ALLREDUCE_FN(allreduce)
+            cb = ALLREDUCE_FN(hook)
         status = _lib.load().serl_learner_update(self._h, C.byref(buffers), C.byref(batch), int(utd_ratio), rin, rout,
                                                  info_out, stream, cb, None, rank, world)
         if err:
@@ -144,6 +151,12 @@ class NativeLearner:
         _lib.call("serl_learner_read_buffer", self._h, int(B), name.encode(), out.data_ptr(),
                   out.numel() * out.element_size(), torch.cuda.current_stream().cuda_stream)
         return out
+
+    def buffer_ptr(self, B, name):
+        """(device address, bytes) of a workspace buffer of the update at minibatch size B."""
+        p, n = C.c_void_p(), C.c_longlong()
+        _lib.call("serl_learner_buffer_ptr", self._h, int(B), name.encode(), C.byref(p), C.byref(n))
+        return p.value, n.value
 
     def workspace_bytes(self) -> int:
         return int(_lib.load().serl_learner_workspace_bytes(self._h))

@@ -253,3 +253,12 @@ def crop_offsets(key, n, row_offset, n_total, pad, out, stream):
 
 def dropout(x, ld, rows, cols, key, keep_prob, row_offset, total_rows, stream):
     call("serl_dropout", x, ld, rows, cols, int(key[0]), int(key[1]), float(keep_prob), row_offset, total_rows, stream)
+
+
+def vice_reward(logits, sigmoids, mean_out, rewards, n, stream):
+    """logits / sigmoids: per camera device pointers ((n,) floats; sigmoids may be None)."""
+    pl, kl = ptr_table(logits)
+    ps = None
+    if sigmoids is not None:
+        ps, ks = ptr_table(sigmoids)
+    call("serl_vice_reward", len(logits), pl, ps, mean_out, rewards, n, stream)

@@ -9,6 +9,8 @@ import pytest
 
 LEARNER_SIDE_IMPORTS = [
     "from serl.agents import SACLearner",
+    "from serl.agents import SACLearner, VICELearner",
+    "from serl.agents import DrQClassifierRewardLearner",
     "from serl.agents import DrQLearner",
     "from serl.agents import DDPGLearner",
     "from serl.agents import PixelDDPGLearner",

@@ -1,0 +1,87 @@
+"""BASELINE config 4's reward networks on the GPU vs the CPU restatement (oracle/reward.py): BinaryClassifier inference
+(`DrQClassifierRewardLearner.classify_reward`), VICE `encode` / `vice_reward` / `update`.  Synthetic frozen backbone (the
+pretrained one is not available offline: backbone parity unpinned)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import agent_to_oracle, assert_info_close, make_pixel_batch, pixel_spaces
+
+pytestmark = pytest.mark.gpu
+KEYS = ("wrist_1", "wrist_2")
+H = W = 64
+RLPD = dict(latent_dim=64, num_qs=10, num_min_qs=2, critic_layer_norm=True, backup_entropy=False, init_temperature=0.1)
+
+
+def _ts_np(ts):
+    lay = ts.store.layout
+    return dict(params=ts.store.numpy_tree(), mu=lay.unflatten(ts.mu.cpu().numpy(), wrap=lambda a: a.copy()),
+                nu=lay.unflatten(ts.nu.cpu().numpy(), wrap=lambda a: a.copy()), count=ts.step)
+
+
+def test_classifier_reward_learner(dev, prec):
+    from oracle import reward as orw
+    from serl_amd.agents import DrQClassifierRewardLearner
+    obs_space, act_space = pixel_spaces(KEYS, H, W, 1, 19, 7)
+    agent = DrQClassifierRewardLearner.create(3, obs_space, act_space, pixel_keys=KEYS, encoder="mobilenet", **RLPD)
+    assert agent.target_entropy == -7.0
+    ostate, ocfg = agent_to_oracle(agent)
+    rng = np.random.default_rng(0)
+    # classify_reward on a single observation scaled to [0, 1] (the scripts' call) and on a batch
+    imgs = {k: rng.integers(0, 256, size=(5, H, W, 3), dtype=np.uint8) for k in KEYS}
+    img01 = {k: v.astype(np.float32) / np.float32(255.0) for k, v in imgs.items()}
+    want = orw.binary_classifier(agent.classifier.store.numpy_tree(), img01, ocfg["backbone"], torch.float64).numpy()
+    got = agent.classify_reward(img01)
+    assert got.shape == (5, 1) and np.abs(got - want).max() <= 2e-4
+    one = agent.classify_reward({k: v[2] for k, v in img01.items()})
+    assert one.shape == (1,) and abs(float(one[0]) - float(want[2, 0])) <= 2e-4
+    assert np.abs(agent.classify_reward(imgs) - want).max() <= 2e-4            # uint8 input: /255 on load
+    # update: key-first augmentation keys, rng not advanced by them
+    B, U = 4, 2
+    batch = make_pixel_batch(rng, B * U, KEYS, H, W, 1, 19, 7, packed=True)
+    collect = []
+    ostate, oinfo = orw.classifier_reward_update(ostate, ocfg, batch, U, collect=collect)
+    new, info = agent.update(batch, U, pixel_keys=KEYS)
+    ws = new._ws(B)
+    for side, okey in (("obs", "observations"), ("next", "next_observations")):
+        for cam in KEYS:
+            got = ws.tensor(f"aug_{side}_{cam}", (B * U, H, W, 3), torch.uint8).cpu().numpy()
+            assert np.array_equal(got.reshape(B * U, H, W, 3, 1), collect[0][okey][cam])
+    assert_info_close(info, oinfo, rtol=1e-3 if prec == "highest" else 5e-3)
+    assert np.array_equal(new.rng, ostate["rng"])
+    assert new.classifier is agent.classifier                                   # never updated by this learner
+
+
+def test_vice_learner_reward_and_update(dev, prec):
+    from oracle import reward as orw
+    from serl_amd.agents import VICELearner
+    obs_space, act_space = pixel_spaces(KEYS, H, W, 1, 19, 7)
+    with pytest.raises(NotImplementedError):
+        VICELearner.create(0, obs_space, act_space, pixel_keys=KEYS)             # encoder="d4pg": NameError upstream
+    agent = VICELearner.create(5, obs_space, act_space, pixel_keys=KEYS, encoder="mobilenet", vice_dropout_rate=0.1, **RLPD)
+    assert list(agent.vice_classifiers) == list(KEYS)
+    ostate, ocfg = agent_to_oracle(agent)
+    ostate["vice"] = {k: _ts_np(v) for k, v in agent.vice_classifiers.items()}
+    rng = np.random.default_rng(1)
+    obs = {k: rng.integers(0, 256, size=(6, H, W, 3, 1), dtype=np.uint8) for k in KEYS}
+    # encode
+    f = agent.encode(obs["wrist_1"]).cpu().numpy()
+    fo = orw.encode(ocfg, obs["wrist_1"], torch.float64).numpy()
+    assert f.shape == fo.shape == (6, 2, 2, 960)
+    assert np.abs(f - fo).max() <= (2e-5 if prec == "highest" else 2e-4) * np.abs(fo).max()
+    # vice_reward
+    agent2, rews = agent.vice_reward(obs, KEYS)
+    ostate2, orews = orw.vice_reward(ostate, ocfg, obs, KEYS, torch.float64)
+    assert list(rews) == ["wrist_1", "wrist_2", "mean"]
+    for k in rews:
+        assert np.abs(rews[k].cpu().numpy() - orews[k].numpy()).max() <= 2e-4, k
+    assert np.array_equal(agent2.rng, ostate2["rng"]) and not np.array_equal(agent2.rng, agent.rng)
+    # update: rewards replaced by the logit of the mean VICE reward of the AUGMENTED observations
+    B, U = 4, 2
+    batch = make_pixel_batch(rng, B * U, KEYS, H, W, 1, 19, 7, packed=True)
+    collect = []
+    ostate, oinfo = orw.vice_update(ostate, ocfg, batch, U, collect=collect)
+    new, info = agent.update(batch, U, pixel_keys=KEYS)
+    assert list(info)[-1] == "vice_rews"
+    assert_info_close(info, oinfo, rtol=1e-3 if prec == "highest" else 5e-3)
+    assert np.array_equal(new.rng, ostate["rng"])
