@@ -89,7 +89,9 @@ int serl_sle_fwd(int ngroups, const void* const* feat, const float* const* ker, 
 int serl_sle_bwd(int ngroups, const float* const* dout, int ldo, const float* const* ker, const void* const* feat,
                  void* const* dfeat, float* const* dker, int B, int HW, int C, int F, int feat_split, void* stream);
 /* Grouped like the convolutions (<= 8 groups = cameras x passes per launch); dfeat / dker may be NULL tables. */
-/* feat_split != 0: feat / dfeat are S-format tensors (below) instead of fp32. */
+/* feat_split bit 0: feat / dfeat are S-format tensors (below) instead of fp32.  serl_sle_bwd folds the ReLU of the last
+ * conv layer into dfeat (dfeat = 0 where feat <= 0); feat_split bit 1 (value 2) turns that mask off (features that are
+ * not a ReLU output: the frozen-backbone embeddings of the VICE gradient penalty). */
 
 /* ---- frozen MobileNetV3-Large feature extractor (inference), the backbone of TwoMobileNetEncoder / MobileNetEncoder:
  * serl/networks/encoders/two_mobilenet_encoder.py:19-34 ((x - mean) / std, mobilenet.apply(params, x, training=False)),
@@ -155,7 +157,8 @@ int serl_fill(float* p, float v, long long n, void* stream);
 
 /* nn.Dropout in training mode on a (rows, cols) block with row stride ld, in place (applied to the gradient with the
  * same key in the backward pass): serl/networks/encoders/two_mobilenet_encoder.py:34, encoded_encoder.py:34.
- * keep = jax.random.bernoulli(key, keep_prob, (total_rows, cols))[row_offset + r][c]. */
+ * keep = jax.random.bernoulli(key, keep_prob, (total_rows, cols))[row_offset + r][c]; row_offset = -1 with total_rows = 1:
+ * every row gets row 0 of a (1, cols) draw (the mask under vmap(grad(...)) with a closed-over rng, vice_learner.py:453-460). */
 int serl_dropout(float* x, int ld, int rows, int cols, unsigned k0, unsigned k1, float keep_prob, int row_offset,
                  int total_rows, void* stream);
 
@@ -163,6 +166,24 @@ int serl_dropout(float* x, int ld, int rows, int cols, unsigned k0, unsigned k1,
  * mean_out[i] = mean over the ncam <= 4 cameras, rewards[i] = log(mean / (1 - mean)); argument tables are host arrays. */
 int serl_vice_reward(int ncam, const float* const* logits, float* const* sigmoids, float* mean_out, float* rewards, int n,
                      void* stream);
+
+/* ---- VICELearner.update_classifier, serl/agents/vice/vice_learner.py:316-474 (csrc/vice.hip)
+ * row_combine: out[r] = wa[r] x[ia[r]] + wb[r] x[ib[r]] over rows of `cols` floats, ia / ib clamped to [0, src_rows)
+ *   (mixup :361, GP interpolation :428).
+ * bce_mixup: loss[0] = mean_i [lam bce(y_i, ya_i) + (1 - lam) bce(y_i, yb_i)] (optax.sigmoid_binary_cross_entropy, :443-449),
+ *   dy = its gradient.  gp_norm: norms[i] = sqrt(sum_j (G_ij^2 + 1e-6)) (:463), alpha[i] = scale 2 (n_i - 1) / (rows n_i).
+ * ln_tangent_fwd / _bwd: forward tangent of [LayerNorm] + activation and its adjoint w.r.t. the tangent AND the primal
+ *   input -- the two pieces of the hand-derived double backward of the gradient penalty (:453-467); acts as serl_ln_act_*. */
+int serl_row_combine(const float* x, int src_rows, const int* ia, const int* ib, const float* wa, const float* wb, float* out,
+                     int rows, long long cols, void* stream);
+int serl_bce_mixup(const float* y, const float* ya, const float* yb, float lam, int n, float* dy, float* loss, void* stream);
+int serl_gp_norm(const float* G, int rows, long long D, float scale, float* alpha, float* norms, void* stream);
+int serl_ln_tangent_fwd(const float* a, const float* xhat, const float* rstd, const float* gamma, const float* y, float* out,
+                        float* w, int R, int N, int use_ln, int act, void* stream);
+int serl_ln_tangent_bwd(const float* outbar, const float* tbar_ext, const float* y, const float* w, const float* a,
+                        const float* xhat, const float* rstd, const float* gamma, float* abar, float* ubar, float* ggamma,
+                        float* nbar, int R, int N, int use_ln, int act, void* stream);
+int serl_axpy(float* y, const float* x, float a, long long n, void* stream);
 
 /* ---- tanh-Gaussian policy head, serl/distributions/tanh_normal.py:29-48 + TFP MultivariateNormalDiag/Tanh;
  * eps = jax.random.normal(key, (total_rows, A))[row_offset : row_offset + B] (threefry2x32, XLA erf_inv). */

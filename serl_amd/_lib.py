@@ -89,6 +89,12 @@ _SIGS = {
     "serl_prng_bits": [c_u, c_u, c_i, c_p],
     "serl_prng_choice": [c_u, c_u, c_i, c_i, c_p],
     "serl_prng_fold_in": [c_u, c_u, c_u, c_p],
+    "serl_row_combine": [c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_ll, c_p],
+    "serl_bce_mixup": [c_p, c_p, c_p, c_f, c_i, c_p, c_p, c_p],
+    "serl_gp_norm": [c_p, c_i, c_ll, c_f, c_p, c_p, c_p],
+    "serl_ln_tangent_fwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    "serl_ln_tangent_bwd": [c_p] * 12 + [c_i, c_i, c_i, c_i, c_p],
+    "serl_axpy": [c_p, c_p, c_f, c_ll, c_p],
     "serl_vice_reward": [c_i, PP, PP, c_p, c_p, c_i, c_p],
     "serl_dropout": [c_p, c_i, c_i, c_i, c_u, c_u, c_f, c_i, c_i, c_p],
 }

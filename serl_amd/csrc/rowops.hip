@@ -696,7 +696,9 @@ __global__ __launch_bounds__(256) void dropout_kernel(float* x, int ld, int rows
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= (long long)rows * cols) return;
   const int r = (int)(i / cols), c = (int)(i - (long long)r * cols);
-  const uint32_t bits = threefry_bits_at(k0, k1, (uint32_t)(row_offset + r) * (uint32_t)cols + (uint32_t)c, total);
+  // row_offset < 0: every row takes row 0 of a (1, cols) draw (the mask vmap(grad(...)) with a closed-over rng applies)
+  const uint32_t gr = row_offset < 0 ? 0u : (uint32_t)(row_offset + r);
+  const uint32_t bits = threefry_bits_at(k0, k1, gr * (uint32_t)cols + (uint32_t)c, total);
   const float u = __uint_as_float((bits >> 9) | 0x3F800000u) - 1.0f;
   float* p = x + (long long)r * ld + c;
   *p = u < keep_prob ? *p / keep_prob : 0.f;
@@ -704,8 +706,9 @@ __global__ __launch_bounds__(256) void dropout_kernel(float* x, int ld, int rows
 extern "C" int serl_dropout(float* x, int ld, int rows, int cols, unsigned k0, unsigned k1, float keep_prob, int row_offset,
                             int total_rows, void* stream) {
   SERL_CHECK_ARG(x && rows >= 1 && cols >= 1 && ld >= cols && keep_prob > 0.f && keep_prob <= 1.f, "dropout: bad args");
-  SERL_CHECK_ARG(row_offset >= 0 && row_offset + rows <= total_rows && (long long)total_rows * cols < (1ll << 32),
-                 "dropout: rows outside the global draw (or more than 2^32 elements)");
+  SERL_CHECK_ARG((row_offset == -1 && total_rows == 1) || (row_offset >= 0 && row_offset + rows <= total_rows),
+                 "dropout: rows outside the global draw");
+  SERL_CHECK_ARG((long long)total_rows * cols < (1ll << 32), "dropout: more than 2^32 elements");
   hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)cdivll((long long)rows * cols, 256)), dim3(256), 0, (hipStream_t)stream, x,
                      ld, rows, cols, k0, k1, keep_prob, row_offset, (uint32_t)((long long)total_rows * cols));
   SERL_CHECK_LAUNCH("dropout");

@@ -18,7 +18,8 @@ __device__ __forceinline__ float feat_at(const void* feat, long long pix, int C,
 #define SLE_F 8
 #define SLE_MAXG 8
 struct SleFwdArgs { const void* feat[SLE_MAXG]; const float* ker[SLE_MAXG]; float* out[SLE_MAXG]; };
-struct SleBwdArgs { const float* dout[SLE_MAXG]; const float* ker[SLE_MAXG]; const void* feat[SLE_MAXG]; void* dfeat[SLE_MAXG]; float* dker[SLE_MAXG]; };
+struct SleBwdArgs { const float* dout[SLE_MAXG]; const float* ker[SLE_MAXG]; const void* feat[SLE_MAXG]; void* dfeat[SLE_MAXG]; float* dker[SLE_MAXG];
+                    int nomask; };   // nomask: the features are not a ReLU output (frozen-backbone embeddings): plain dfeat
 
 // thread = (b, c); grid.y splits hw into chunks whose partials are summed in a fixed order by the caller
 // (nchunk == 1 for the 7x7 maps of the stride-2 encoder).
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(256) void sle_bwd_data_kernel(const SleBwdArgs a, i
     s += d[1] * k0.y; s += d[2] * k0.z; s += d[3] * k0.w;
     s += d[4] * k1.x; s += d[5] * k1.y; s += d[6] * k1.z; s += d[7] * k1.w;
     const long long pix = (long long)b * HW + hw;
-    const float v = feat_at<SPLIT>(feat, pix, C, c) > 0.f ? s : 0.f;
+    const float v = (a.nomask || feat_at<SPLIT>(feat, pix, C, c) > 0.f) ? s : 0.f;
     if constexpr (SPLIT) {
       uint32_t h, l;
       split_pair(v, 0.f, h, l);
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(256) void sle_bwd_data_sliced_kernel(const SleBwdAr
       s += d[j][1] * k0.y; s += d[j][2] * k0.z; s += d[j][3] * k0.w;
       s += d[j][4] * k1.x; s += d[j][5] * k1.y; s += d[j][6] * k1.z; s += d[j][7] * k1.w;
       const long long pix = (long long)(b0 + j) * HW + hw;
-      const float v = feat_at<SPLIT>(feat, pix, C, c) > 0.f ? s : 0.f;
+      const float v = (a.nomask || feat_at<SPLIT>(feat, pix, C, c) > 0.f) ? s : 0.f;
       if constexpr (SPLIT) {
         uint32_t h, l;
         split_pair(v, 0.f, h, l);
@@ -244,6 +245,8 @@ extern "C" int serl_sle_bwd(int ngroups, const float* const* dout, int ldo, cons
   SERL_CHECK_ARG(F == SLE_F, "sle_bwd: num_features must be %d", SLE_F);
   hipStream_t st = (hipStream_t)stream;
   SleBwdArgs a;
+  a.nomask = (feat_split & 2) != 0;
+  feat_split &= 1;
   for (int i = 0; i < ngroups; ++i) {
     SERL_CHECK_ARG(dout[i] && ker[i] && feat[i] && (!dfeat || dfeat[i]) && (!dker || dker[i]), "sle_bwd: null pointer");
     a.dout[i] = dout[i]; a.ker[i] = ker[i]; a.feat[i] = feat[i];

@@ -224,7 +224,7 @@ def sle_bwd(douts, ldo, kers, feats, dfeats, dkers, B, HW, C, F, stream, feat_sp
         pdf, kdf = ptr_table(_as_list(dfeats))
     if dkers is not None:
         pdk, kdk = ptr_table(_as_list(dkers))
-    call("serl_sle_bwd", len(douts), pd, ldo, pk, pf, pdf, pdk, B, HW, C, F, int(feat_split), stream)
+    call("serl_sle_bwd", len(douts), pd, ldo, pk, pf, pdf, pdk, B, HW, C, F, int(feat_split), stream)   # bit 1: no ReLU mask
 
 
 def gather_crop_frames(frames, cap, indx, T, t0, off, out, n, H, W, S, pad, stream):
@@ -262,3 +262,28 @@ def vice_reward(logits, sigmoids, mean_out, rewards, n, stream):
     if sigmoids is not None:
         ps, ks = ptr_table(sigmoids)
     call("serl_vice_reward", len(logits), pl, ps, mean_out, rewards, n, stream)
+
+
+def row_combine(x, src_rows, ia, ib, wa, wb, out, rows, cols, stream):
+    call("serl_row_combine", x, src_rows, ia, ib, wa, wb, out, rows, cols, stream)
+
+
+def bce_mixup(y, ya, yb, lam, n, dy, loss, stream):
+    call("serl_bce_mixup", y, ya, yb, float(lam), n, dy, loss, stream)
+
+
+def gp_norm(G, rows, D, scale, alpha, norms, stream):
+    call("serl_gp_norm", G, rows, D, float(scale), alpha, norms, stream)
+
+
+def ln_tangent_fwd(a, xhat, rstd, gamma, y, out, w, R, N, use_ln, act, stream):
+    call("serl_ln_tangent_fwd", a, xhat, rstd, gamma, y, out, w, R, N, int(use_ln), act, stream)
+
+
+def ln_tangent_bwd(outbar, tbar_ext, y, w, a, xhat, rstd, gamma, abar, ubar, ggamma, nbar, R, N, use_ln, act, stream):
+    call("serl_ln_tangent_bwd", outbar, tbar_ext, y, w, a, xhat, rstd, gamma, abar, ubar, ggamma, nbar, R, N, int(use_ln),
+         act, stream)
+
+
+def axpy(y, x, a, n, stream):
+    call("serl_axpy", y, x, float(a), n, stream)

@@ -85,3 +85,43 @@ def test_vice_learner_reward_and_update(dev, prec):
     assert list(info)[-1] == "vice_rews"
     assert_info_close(info, oinfo, rtol=1e-3 if prec == "highest" else 5e-3)
     assert np.array_equal(new.rng, ostate["rng"])
+
+
+@pytest.mark.parametrize("layer_norm", [True, False])
+def test_vice_update_classifier(dev, layer_norm):
+    """vice_learner.py:316-474 at precision "highest": goal sampling, augmentation, mixup, label smoothing, mixup BCE and the
+    gradient penalty, whose parameter gradient is a hand-derived double backward on the GPU and torch's
+    autograd-of-autograd in the oracle.  Gradients of both cameras vs the float64 oracle, logged scalars, rng, Adam step."""
+    import serl_amd
+    from helpers import assert_tree_close
+    from oracle import reward as orw
+    from serl_amd.agents import VICELearner
+    serl_amd.set_matmul_precision("highest")
+    try:
+        obs_space, act_space = pixel_spaces(KEYS, H, W, 1, 19, 7)
+        rng = np.random.default_rng(2)
+        pool = {k: rng.integers(0, 256, size=(9, H, W, 3, 1), dtype=np.uint8) for k in KEYS}
+        kw = dict(RLPD, critic_layer_norm=layer_norm)
+        agent = VICELearner.create(8, obs_space, act_space, pixel_keys=KEYS, encoder="mobilenet", vice_dropout_rate=0.1,
+                                   vice_goal_pool=pool, **kw)
+        ostate, ocfg = agent_to_oracle(agent)
+        ostate["vice"] = {k: _ts_np(v) for k, v in agent.vice_classifiers.items()}
+        ocfg.update(vice_lr=3e-4, vice_dropout_rate=0.1)
+        B = 6
+        batch = make_pixel_batch(rng, B, KEYS, H, W, 1, 19, 7, packed=True)
+        collect = []
+        ostate, oinfo = orw.update_classifier(ostate, ocfg, batch, KEYS, pool, dtype=torch.float64, collect=collect)
+        new, info = agent.update_classifier(batch, KEYS)
+        assert set(info) == set(oinfo)
+        for k in oinfo:
+            assert abs(info[k] - oinfo[k]) <= 1e-3 * max(abs(oinfo[k]), 1e-2), (k, info[k], oinfo[k])
+        assert np.array_equal(new.rng, ostate["rng"])
+        for c in collect:
+            got = agent._shared["vice_last_grads"][c["camera"]].numpy_tree()
+            assert_tree_close(got, c["grads"], rtol=2e-3, l2_rtol=2e-3, what=f"classifier grads {c['camera']}")
+        for k in KEYS:
+            assert new.vice_classifiers[k].step == 1 and agent.vice_classifiers[k].step == 0
+            got = new.vice_classifiers[k].store.numpy_tree()
+            assert_tree_close(got, ostate["vice"][k]["params"], atol=2.5 * 3e-4, mean_atol=2e-5, what=f"params {k}")
+    finally:
+        serl_amd.set_matmul_precision("bf16_3x")
