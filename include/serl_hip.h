@@ -66,6 +66,11 @@ int serl_convs_fwd(int ngroups, const void* const* x, const void* const* wf, con
  * "y[pixel][n+j] != 0" -- the ReLU mask for the data gradient of the next layer, 32x smaller than y's hi plane.
  * serl_convs_dgrad masks dx with xact: the layer's post-ReLU input in S format (xact_bits = 0), or that byte mask
  * (xact_bits = 1); xact NULL or a NULL entry: no mask. */
+/* 3x3 stride-2 layers whose rows fit are run by the "patch" kernels (csrc/pconv.h: a band of input rows staged once in
+ * LDS, all taps read from there; bit-identical output).  enable = 0 keeps every layer on the im2col kernels -- for A/B
+ * measurements and the bit-identity test of the two paths.  Process-wide; no counterpart in the reference (XLA picks
+ * its convolution algorithm itself, two_d4pg_encoder.py:30-38). */
+int serl_convs_set_patch_kernels(int enable);
 int serl_convs_dgrad(int ngroups, const void* const* dz, const void* const* wd, const void* const* xact,
                      void* const* dx, int B, int IH, int IW, int C, int KH, int KW, int stride, int F, int xact_bits,
                      void* stream);

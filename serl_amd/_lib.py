@@ -61,6 +61,7 @@ _SIGS = {
     "serl_convs_wgrad": [c_i, PP, PP, PP, PP, c_p, c_ll, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "serl_convs_wgrad_noalloc": [c_i, PP, PP, PP, PP, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "serl_convs_wgrad_noalloc_max_bytes": [],
+    "serl_convs_set_patch_kernels": [c_i],
     "serl_gather_crop_frames": [c_p, c_ll, c_p, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
     "serl_gather_crop_packed": [c_p, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
     "serl_gather_window": [c_p, c_ll, c_p, c_p, c_i, c_i, c_i, c_p],
@@ -131,6 +132,8 @@ def load():
     lib.serl_last_error.argtypes = []
     lib.serl_last_error.restype = C.c_char_p
     _lib = lib
+    if os.environ.get("SERL_AMD_CONV_PATCH") == "0":       # A/B measurements: every conv layer on the im2col kernels
+        lib.serl_convs_set_patch_kernels(0)
     env = os.environ.get("SERL_AMD_MATMUL_PRECISION")
     if env is not None:
         from . import set_matmul_precision

@@ -8,6 +8,7 @@
 
 #include "conv_geom.h"
 #include "sgemm.h"
+#include "pconv.h"
 
 typedef unsigned short ushort_t;
 
@@ -574,6 +575,14 @@ extern "C" int serl_convs_prep_weights_multi(int njobs, const float* const* w, v
   return SERL_OK;
 }
 
+// The patch kernels (pconv.h) are chosen wherever the layer fits them; 0 keeps every layer on the im2col kernels (A/B
+// measurements and the bit-identity test of the two paths).  Process-wide.
+static int g_patch_kernels = 1;
+extern "C" int serl_convs_set_patch_kernels(int enable) {
+  g_patch_kernels = enable ? 1 : 0;
+  return SERL_OK;
+}
+
 extern "C" int serl_convs_fwd(int ngroups, const void* const* x, const void* const* wf, const float* const* bias,
                               void* const* y, int in_u8, int B, int IH, int IW, int C, int KH, int KW, int stride, int F,
                               int relu, void* const* rmask, void* stream) {
@@ -585,6 +594,24 @@ extern "C" int serl_convs_fwd(int ngroups, const void* const* x, const void* con
                  "convs_fwd: S-format tensors must be 16-byte aligned");
   const int M = B * g.OH * g.OW;
   hipStream_t st = (hipStream_t)stream;
+  if (g_patch_kernels && !in_u8 && KH == 3 && KW == 3 && stride == 2) {
+    // 3x3 stride-2 layers whose row fits the patch layout: input rows staged once in LDS (pconv.h), bit-identical output
+    const bool fit32 = C == 32 && F == 64 && g.OW <= 32 && (IW + 1) / 2 <= 32;
+    // (C = 64 -> 128 at OW <= 16 fits too, a C = 64 patch with a streamed weight slab, but measured 2x slower than im2col: 48 pixels
+    //  per block against 295 KB of weights; that layer is not over-fetch bound)
+    const bool fit16 = false;
+    if (fit32 || fit16) {
+      PConvFwdArgs a;
+      a.B = B; a.IH = IH; a.IW = IW; a.OH = g.OH; a.OW = g.OW; a.relu = relu;
+      a.nbands = cdiv(g.OH, fit32 ? 4 : 3);
+      a.d_iw = make_fastdiv(IW); a.d_bands = make_fastdiv(a.nbands);
+      for (int i = 0; i < ngroups; ++i) {
+        a.x[i] = (const ushort_t*)x[i]; a.wf[i] = (const ushort_t*)wf[i]; a.bias[i] = bias[i]; a.y[i] = (ushort_t*)y[i];
+        a.rmask[i] = rmask ? (unsigned char*)rmask[i] : nullptr;
+      }
+      return pconv_fwd_launch<PFwdCfg<32, 64, 4, 32>>(a, ngroups, st, "convs_fwd(patch)");
+    }
+  }
 #define FILL(p)                                                                                              \
   p.g = g; p.relu = relu; p.Kp = s_kp(in_u8, KH, KW, C); p.scale = in_u8 ? 1.0f / 255.0f : 1.0f;             \
   p.d_c = make_fastdiv(C); p.d_kw = make_fastdiv(KW);                                                        \

@@ -1,0 +1,292 @@
+// "Patch" convolutions for the 3x3 stride-2 layers of the conv encoder on S-format tensors (sgemm.h).
+//
+// The implicit-GEMM kernels of convs.hip gather every tap of the im2col matrix from global memory: each input line is
+// fetched 2.25 times (9 taps / stride^2), and because the blocks in flight on an XCD touch ~20 MB against a 4 MB L2
+// most of those re-reads miss (measured 1.5-1.7x the algorithmic bytes on the L2-miss side, profiles/r01_v23_traffic.json).
+// Here a block owns a band of R output rows of ONE image: it copies the 2R+1 input rows it needs into LDS once (a
+// contiguous span of global memory, since every row is taken at full width), and all nine taps of the K loop read their
+// MFMA A fragments from that patch.  Input over-fetch is (2R+1)/2R by construction.  Same math, same k order and the
+// same MFMA sequence per k16 step as sgemm_kernel<ConvFwdS>: the outputs are bit-identical to it.
+//
+// Patch layout in LDS: record = one pixel = hi[C] lo[C] bf16 (4C bytes, as in global memory), records of a row split by
+// the parity of ix ([row][ix & 1][ix >> 1]) so that the 32 (or 16) lanes of a fragment read -- consecutive ox, i.e. ix
+// two apart -- touch consecutive records; the 16-byte chunk index inside a record is XOR-swizzled with the record index
+// so that 16 consecutive records land in 16 distinct 16-byte bank groups (ds_read_b128 serves 16 lanes per pass).
+// One persistent block of 8 waves per CU walks a contiguous run of (image, band) items of one group with TWO patch
+// buffers: the LDS-DMA (global_load_lds_dwordx4, no staging registers) of item i+1 is in flight while item i is
+// multiplied and stored, so HBM latency is hidden inside the block.
+// Weights (B operand): every wave
+// keeps the MFMA B fragments of its N tile for the WHOLE K range in registers (9C/16 * 8 VGPRs): the weight matrix is
+// read once per block with coalesced loads, transposed into fragment order through the (still empty) LDS, and the K loop
+// has no global load and no barrier in it.  (Streaming a k16 weight slab through LDS per step exposed an L2 round trip
+// per step, loading fragments straight from the [F][2][K] layout made every lane fetch its own cache line: both measured
+// slower than the im2col kernel.)
+#pragma once
+#include "conv_geom.h"
+#include "sgemm.h"
+
+struct PConvFwdArgs {
+  const unsigned short* x[MAXG];
+  const unsigned short* wf[MAXG];     // S format [F][2][9C], k = (ky, kx, c)
+  const float* bias[MAXG];
+  unsigned short* y[MAXG];
+  unsigned char* rmask[MAXG];
+  int B, IH, IW, OH, OW, nbands, relu;
+  FastDiv d_iw, d_bands;
+};
+
+// C, F: channels in / out; R: output rows per item; OWP: padded output width (power of two, 32 % OWP == 0).
+// 8 waves = (M tiles) x (N tiles) of an item, one 32 x 32 accumulator per wave.
+template <int C_, int F_, int R_, int OWP_>
+struct PFwdCfg {
+  static constexpr int C = C_, F = F_, R = R_, OWP = OWP_;
+  static constexpr int NT = 512;
+  static constexpr int REC = 4 * C;                 // bytes per pixel record
+  static constexpr int NCH = C / 4;                 // 16-byte chunks per record
+  static constexpr int NR = 2 * R + 1;              // patch rows
+  static constexpr int ROWB = 2 * OWP * REC;        // bytes per patch row (two parity regions of OWP records)
+  static constexpr int PATCH = NR * ROWB;
+  static constexpr int SLOTS = PATCH / 16;
+  static constexpr int MT = (R * OWP + 31) / 32;    // 32-row MFMA tiles
+  static constexpr int NTL = F / 32;
+  static constexpr int KP = 9 * C;
+  static constexpr int WROW = KP * 2 + 16;          // bytes per row of the weight transposition image [plane][f][K]: odd in 16-B units
+  static constexpr int WIMG = 2 * F * WROW;
+  static constexpr int EPI = MT * 32 * (F + 4) * 4;
+  static constexpr int LDS = 2 * PATCH;
+  static_assert(MT * NTL == 8, "one accumulator tile per wave, 8 waves");
+  static_assert(C % 16 == 0 && F % 32 == 0 && 32 % OWP == 0 && SLOTS % NT == 0, "shape");
+  static_assert((KP / 8) % 2 == 0 && ((WROW / 16) & 1) == 1, "weight image rows");
+  static_assert(EPI <= PATCH && WIMG <= LDS && LDS <= 160 * 1024, "LDS");
+};
+
+typedef __attribute__((address_space(1))) const void* pconv_gptr_t;
+typedef __attribute__((address_space(3))) void* pconv_lptr_t;
+
+template <int REC> __device__ __forceinline__ int pconv_swz(int j) { return REC == 128 ? ((j >> 1) & 7) : (j & 15); }
+
+// workgroup barrier that waits for this wave's LDS operations only: an LDS-DMA in flight (vmcnt) stays in flight
+__device__ __forceinline__ void pconv_lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+}
+
+template <class G>
+__global__ __launch_bounds__(512, 1) void pconv_fwd_kernel(const PConvFwdArgs a) {
+  constexpr int C = G::C, F = G::F, R = G::R, OWP = G::OWP, NT = G::NT;
+  constexpr int REC = G::REC, NCH = G::NCH, ROWB = G::ROWB, PARB = OWP * REC;
+  constexpr int RPT = 32 / OWP;
+  constexpr int KS = C / 16, NS = 9 * KS;
+  constexpr int Kp = G::KP, WROW = G::WROW;
+  extern __shared__ __attribute__((aligned(16))) unsigned char p_smem[];
+
+  const int z = blockIdx.z;
+  const int nitems = a.B * a.nbands;
+  const int per = (nitems + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int it0 = blockIdx.x * per, it1 = min(nitems, it0 + per);
+  if (it0 >= it1) return;                                   // block-uniform, before any barrier
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int wm = wid / G::NTL, wn = wid - wm * G::NTL;
+
+  // ---- weights: contiguous [F][2][Kp] bf16 -> LDS image [plane][f][Kp (+8)] -> B fragments of this wave's N tile:
+  // lane (r, h) holds k = 16 s + 8 h .. + 7 of column f = 32 wn + r, for every k16 step s
+  bf16x8_t rbh[NS], rbl[NS];
+  {
+    constexpr int CPR = Kp / 8;                             // 16-byte chunks per (f, plane) row
+    constexpr int NWC = 2 * F * CPR, NWL = (NWC + NT - 1) / NT;
+    const char* wsrc = reinterpret_cast<const char*>(a.wf[z]);
+    u32x4_t wv[NWL];
+#pragma unroll
+    for (int i = 0; i < NWL; ++i) {
+      const int q = tid + i * NT;
+      wv[i] = *reinterpret_cast<const u32x4_t*>(q < NWC ? wsrc + (size_t)q * 16 : reinterpret_cast<const char*>(g_zero_page));
+    }
+#pragma unroll
+    for (int i = 0; i < NWL; ++i) {
+      const int q = tid + i * NT;
+      if (q < NWC) {
+        const int row = q / CPR, kc = q - row * CPR;        // row = f * 2 + plane
+        *reinterpret_cast<u32x4_t*>(p_smem + ((row & 1) * F + (row >> 1)) * WROW + kc * 16) = wv[i];
+      }
+    }
+    __syncthreads();
+    const unsigned char* wrow = p_smem + (wn * 32 + r) * WROW + h * 16;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      rbh[s] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(wrow + s * 32));
+      rbl[s] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(wrow + F * WROW + s * 32));
+    }
+    __syncthreads();
+  }
+
+  // ---- fragment addresses of this lane (the same for every item)
+  const int ox = r & (OWP - 1);
+  const int arow = 2 * min(wm * RPT + r / OWP, R - 1) * ROWB;     // padding rows repeat the last row (never stored)
+  const int rec0 = ox * REC, rec1 = (ox + 1) * REC;
+  const int sw0 = pconv_swz<REC>(ox) << 4, sw1 = pconv_swz<REC>(ox + 1) << 4;
+  constexpr int LDC = F + 4;
+  constexpr int CH = F / 8, RPP = NT / CH;
+  const int n = (tid % CH) * 8;
+  float bs[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) bs[j] = a.bias[z][n + j];
+  unsigned short* const out = a.y[z];
+  unsigned char* const mk = a.rmask[z];
+
+  // LDS-DMA of one item's patch: rows 2*oy0 .. 2*oy0 + 2*rows of image b are a contiguous span of global memory.  The
+  // destination of a wave-instruction is 64 consecutive 16-byte slots, so the parity split and the chunk swizzle are
+  // applied to the per-lane SOURCE address: slot l = (row, parity, j, swizzled chunk) in the patch's linear order.
+  constexpr int NDMA = G::SLOTS / NT;
+  struct DmaSrc { const char* src; int nrows; };
+  auto dma_src = [&](int item) {
+    const int b = (int)fd_div((uint32_t)item, a.d_bands), band = item - b * a.nbands;
+    const int oy0 = band * R;
+    DmaSrc d;
+    d.nrows = 2 * min(R, a.OH - oy0) + 1;
+    d.src = reinterpret_cast<const char*>(a.x[z]) + ((size_t)(b * a.IH + 2 * oy0) * a.IW) * REC;
+    return d;
+  };
+  auto dma_piece = [&](const DmaSrc& d, unsigned char* patch, int i) {      // piece i of NDMA: 8 waves x 64 slots
+    const int l = (i * 8 + wid) * 64 + lane;
+    const int rec = l / NCH, chp = l & (NCH - 1);
+    const int rr = rec / (2 * OWP), par = (rec / OWP) & 1, j = rec & (OWP - 1);
+    const int ix = 2 * j + par;
+    const bool ok = rr < d.nrows && ix < a.IW;
+    const char* g = ok ? d.src + (size_t)(((rr * a.IW + ix) * NCH + (chp ^ pconv_swz<REC>(j))) * 16)
+                       : reinterpret_cast<const char*>(g_zero_page);
+    __builtin_amdgcn_global_load_lds((pconv_gptr_t)g, (pconv_lptr_t)(patch + (i * 8 + wid) * 1024), 16, 0, 0);
+  };
+
+  {
+    const DmaSrc d0 = dma_src(it0);
+#pragma unroll 1
+    for (int i = 0; i < NDMA; ++i) dma_piece(d0, p_smem, i);
+  }
+  int pb = 0;
+  for (int item = it0; item < it1; ++item, pb ^= 1) {
+    unsigned char* const patch = p_smem + pb * G::PATCH;
+    const int b = (int)fd_div((uint32_t)item, a.d_bands), band = item - b * a.nbands;
+    const int oy0 = band * R;
+    const int rows_here = min(R, a.OH - oy0);
+    // this item's patch has landed (vmcnt(0) of every wave -- written out: hipcc's __syncthreads() leaves the wait to
+    // whichever LDS read comes first, and a wave whose lanes all skip the output loop has none), and every wave is
+    // done with the previous item's output tile, which lives in the other buffer
+    // The stores of the previous item are younger than this patch's DMA and vmcnt retires in order, so the wait leaves
+    // exactly those stores in flight (2, or 3 with a byte mask, per pass).
+    static_assert(G::MT * 32 / RPP == 2, "store count of the counted wait");
+    if (item == it0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else if (mk != nullptr) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // the next item's DMA pieces are issued between the taps of the K loop: their address arithmetic (VALU) and issue
+    // slots hide under the MFMAs instead of forming a phase of their own
+    const bool more = item + 1 < it1;
+    const DmaSrc dn = dma_src(more ? item + 1 : item);
+    unsigned char* const npatch = p_smem + (pb ^ 1) * G::PATCH;
+
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#ifdef PCONV_NO_MMA
+    if (item == it0)
+#endif
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ky = tap / 3, kx = tap - 3 * ky;
+      const int tapoff = arow + ky * ROWB + (kx & 1) * PARB + (kx == 2 ? rec1 : rec0);
+      const int sw = kx == 2 ? sw1 : sw0;
+#pragma unroll
+      for (int kc = 0; kc < KS; ++kc) {
+        const int chh = ((kc * 2 + h) << 4) ^ sw, chl = ((kc * 2 + h + C / 8) << 4) ^ sw;
+        const bf16x8_t ah = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(patch + tapoff + chh));
+        const bf16x8_t al = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(patch + tapoff + chl));
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, rbh[tap * KS + kc], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, rbl[tap * KS + kc], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, rbh[tap * KS + kc], acc, 0, 0, 0);
+      }
+#ifndef PCONV_NO_DMA
+      if (more) {
+#pragma unroll
+        for (int i = tap * NDMA / 9; i < (tap + 1) * NDMA / 9; ++i) dma_piece(dn, npatch, i);
+      }
+#endif
+    }
+    pconv_lds_barrier();                   // every wave is done with the patch before the output tile overwrites it
+
+    // ---- S-format output through an fp32 tile in LDS (as sgemm.h): 8 consecutive channels of one pixel per thread
+    float* const Cs = reinterpret_cast<float*>(patch);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int row = wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+      Cs[row * LDC + wn * 32 + r] = acc[q];
+    }
+    pconv_lds_barrier();
+    // Every thread runs every pass and issues the same number of stores: rows past the band's end and the padding
+    // column are redirected to the last valid row / column (they store that pixel's values a second time), so the
+    // wait at the top of the next item can be a COUNT that leaves exactly these stores in flight.
+    const uint32_t cs_base = (uint32_t)(size_t)(pconv_lptr_t)Cs;
+#pragma unroll
+    for (int pass = 0; pass < G::MT * 32 / RPP; ++pass) {
+      const int row0 = tid / CH + pass * RPP;
+      const int oyl = min(row0 / OWP, rows_here - 1), oxx = min(row0 & (OWP - 1), a.OW - 1);
+      const int row = oyl * OWP + oxx;
+      const size_t pix = (size_t)(b * a.OH + oy0 + oyl) * a.OW + oxx;
+      // LDS reads by hand: hipcc puts vmcnt(0) in front of a read it cannot tell apart from the DMA's destination,
+      // which would wait for the NEXT item's patch here
+      u32x4_t c0, c1;
+      asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&v"(c0), "=&v"(c1) : "v"(cs_base + (uint32_t)(row * LDC + n) * 4u) : "memory");
+      float v[8] = {__uint_as_float(c0[0]), __uint_as_float(c0[1]), __uint_as_float(c0[2]), __uint_as_float(c0[3]),
+                    __uint_as_float(c1[0]), __uint_as_float(c1[1]), __uint_as_float(c1[2]), __uint_as_float(c1[3])};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        v[j] = fmaf(v[j], 1.0f, bs[j]);
+        if (a.relu) v[j] = fmaxf(v[j], 0.f);
+      }
+      u32x4_t hi, lo;
+      uint32_t hh, ll;
+      split_pair(v[0], v[1], hh, ll); hi[0] = hh; lo[0] = ll;
+      split_pair(v[2], v[3], hh, ll); hi[1] = hh; lo[1] = ll;
+      split_pair(v[4], v[5], hh, ll); hi[2] = hh; lo[2] = ll;
+      split_pair(v[6], v[7], hh, ll); hi[3] = hh; lo[3] = ll;
+      unsigned short* dst = out + pix * 2 * F + n;
+#ifdef PCONV_NO_STORE
+      if (item != it0) continue;
+#endif
+      *reinterpret_cast<u32x4_t*>(dst) = hi;
+      *reinterpret_cast<u32x4_t*>(dst + F) = lo;
+      if (mk != nullptr) {
+        uint32_t bits = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          bits |= (hi[j] & 0x7fffu) ? (1u << (2 * j)) : 0u;
+          bits |= (hi[j] & 0x7fff0000u) ? (2u << (2 * j)) : 0u;
+        }
+        mk[pix * (F >> 3) + (n >> 3)] = (unsigned char)bits;
+      }
+    }
+  }
+}
+
+// one persistent block per CU over all groups
+template <class G>
+static int pconv_fwd_launch(const PConvFwdArgs& a, int ngroups, hipStream_t st, const char* name) {
+  static bool opted[64] = {};
+  static int ncu[64] = {};
+  int dev = 0;
+  SERL_CHECK_HIP(hipGetDevice(&dev), name);
+  SERL_CHECK_ARG(dev >= 0 && dev < 64, "%s: device ordinal %d out of range", name, dev);
+  if (!opted[dev]) {
+    SERL_CHECK_HIP(hipFuncSetAttribute((const void*)pconv_fwd_kernel<G>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS), name);
+    SERL_CHECK_HIP(hipDeviceGetAttribute(&ncu[dev], hipDeviceAttributeMultiprocessorCount, dev), name);
+    opted[dev] = true;
+  }
+  const int nitems = a.B * a.nbands;
+  int gx = (ncu[dev] > 0 ? ncu[dev] : 256) / ngroups;
+  if (gx < 1) gx = 1;
+  if (gx > nitems) gx = nitems;
+  hipLaunchKernelGGL((pconv_fwd_kernel<G>), dim3(gx, 1, ngroups), dim3(G::NT), G::LDS, st, a);
+  SERL_CHECK_LAUNCH(name);
+  return SERL_OK;
+}

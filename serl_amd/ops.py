@@ -96,6 +96,11 @@ def convs_fwd(xs, wfs, bs, ys, in_u8, B, IH, IW, C, KH, KW, stride, F, relu, str
     call("serl_convs_fwd", n, px, pw, pb, py, int(in_u8), B, IH, IW, C, KH, KW, stride, F, int(relu), pm, stream)
 
 
+def convs_set_patch_kernels(enable):
+    """Process-wide: 3x3 stride-2 layers on the LDS-patch kernels (default) or on the im2col kernels only."""
+    call("serl_convs_set_patch_kernels", int(bool(enable)))
+
+
 def convs_dgrad(dzs, wds, xacts, dxs, B, IH, IW, C, KH, KW, stride, F, stream, xact_bits=False):
     n = len(dzs)
     pz, kz = ptr_table(dzs); pw, kw = ptr_table(wds); pa, ka = ptr_table(xacts); pd, kd = ptr_table(dxs)

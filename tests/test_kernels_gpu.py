@@ -228,6 +228,56 @@ def test_convs_fwd_dgrad_wgrad(dev, case):
             close(got, ref_dx, rtol=tol, what=f"convs dgrad g{g}")
 
 
+@pytest.mark.parametrize("case", [(3, 63, 63, 32, 64), (2, 64, 63, 32, 64), (3, 31, 31, 64, 128), (2, 29, 32, 64, 128),
+                                  (1, 9, 11, 32, 64)])
+def test_patch_conv_bit_identical_to_im2col(dev, case):
+    """The LDS-patch kernels (csrc/pconv.h) keep the k order and the MFMA sequence of the im2col kernels: outputs,
+    ReLU byte masks and data gradients must be bit-identical, over full and ragged bands, odd/even widths and a row
+    narrower than the lane tile."""
+    ops = _ops()
+    B, IH, IW, Cin, F = case
+    K, S, G = 3, 2, 3
+    rng = np.random.default_rng(7)
+    st = ops.current_stream()
+    OH, OW = (IH - K) // S + 1, (IW - K) // S + 1
+    wb = ops.convs_weight_bytes(False, K, K, Cin, F)
+    xs, wfs, wds, bs, keep, dzs, xm = [], [], [], [], [], [], []
+    for g in range(G):
+        x = np.maximum(rng.standard_normal((B, IH, IW, Cin)).astype(np.float32), 0)
+        buf, _ = _to_s(ops, dv(x, dev), B * IH * IW, Cin, st)
+        xs.append(buf)
+        xm.append(dv(np.packbits(x.reshape(-1, Cin) != 0, axis=1, bitorder="little").reshape(-1), dev))
+        keep.append(dv((rng.standard_normal((K, K, Cin, F)) * 0.1).astype(np.float32), dev))
+        wfs.append(torch.full((wb // 2,), -1, dtype=torch.int16, device=dev))
+        wds.append(torch.full((K * K * Cin * F * 2,), -1, dtype=torch.int16, device=dev))
+        bs.append(dv((rng.standard_normal(F) * 0.1).astype(np.float32), dev))
+        buf, _ = _to_s(ops, dv(rng.standard_normal((B, OH, OW, F)).astype(np.float32), dev), B * OH * OW, F, st)
+        dzs.append(buf)
+    ops.convs_prep_weights([t.data_ptr() for t in keep], [t.data_ptr() for t in wfs], [t.data_ptr() for t in wds],
+                           False, K, K, Cin, F, st)
+    out = {}
+    try:
+        for mode in (0, 1):
+            ops.convs_set_patch_kernels(mode)
+            ys = [torch.full((B * OH * OW * F * 2,), -1, dtype=torch.int16, device=dev) for _ in range(G)]
+            rm = [torch.full((B * OH * OW * F // 8,), 0xAA, dtype=torch.uint8, device=dev) for _ in range(G)]
+            dxs = [torch.full((B * IH * IW * Cin * 2,), -1, dtype=torch.int16, device=dev) for _ in range(G)]
+            ops.convs_fwd([t.data_ptr() for t in xs], [t.data_ptr() for t in wfs], [t.data_ptr() for t in bs],
+                          [t.data_ptr() for t in ys], False, B, IH, IW, Cin, K, K, S, F, True, st,
+                          rmasks=[rm[0].data_ptr(), 0, rm[2].data_ptr()])
+            ops.convs_dgrad([t.data_ptr() for t in dzs], [t.data_ptr() for t in wds], [t.data_ptr() for t in xm],
+                            [t.data_ptr() for t in dxs], B, IH, IW, Cin, K, K, S, F, st, xact_bits=True)
+            torch.cuda.synchronize()
+            out[mode] = (ys, rm, dxs)
+    finally:
+        ops.convs_set_patch_kernels(1)
+    for g in range(G):
+        assert torch.equal(out[0][0][g], out[1][0][g]), f"forward differs, group {g}"
+        assert torch.equal(out[0][1][g], out[1][1][g]), f"ReLU byte mask differs, group {g}"
+        assert torch.equal(out[0][2][g], out[1][2][g]), f"data gradient differs, group {g}"
+    assert bool((out[1][1][1] == 0xAA).all()), "a NULL mask entry must not be written"
+
+
 # ---------------------------------------------------------------------------------- igemm: dense
 @pytest.mark.parametrize("dims", [(3, 70, 83, 45), (2, 64, 96, 128)])   # ragged (scalar loads) / aligned (float4 loads)
 def test_gemm_variants(dev, prec, dims):

@@ -14,6 +14,8 @@ NITER = int(os.environ.get("BENCH_N", "20"))
 FWD_G = int(os.environ.get("BENCH_FWD_G", "4"))   # forward groups per launch: 2 cameras x (target, critic) passes
 MODE = os.environ.get("BENCH_MODE", "s")         # "s": S-format entry points (serl_convs_*); "f": serl_conv2d_*
 dev = torch.device("cuda")
+if os.environ.get("BENCH_PATCH") is not None:   # 0: im2col kernels only, 1 (library default): patch kernels where they fit
+    ops.convs_set_patch_kernels(int(os.environ["BENCH_PATCH"]))
 LAYERS = [(128, 9, 32), (63, 32, 64), (31, 64, 128), (15, 128, 256)]   # IH, C, F  (3x3, stride 2)
 st = ops.current_stream()
 
