@@ -634,6 +634,24 @@ extern "C" int serl_convs_dgrad(int ngroups, const void* const* dz, const void* 
   SERL_CHECK_ARG(F % 8 == 0 && C % 8 == 0, "convs_dgrad: need C %% 8 == 0 and F %% 8 == 0");
   SERL_CHECK_ARG(all_aligned16(dz, ngroups) && all_aligned16(wd, ngroups) && all_aligned16(dx, ngroups),
                  "convs_dgrad: S-format tensors must be 16-byte aligned");
+  if (g_patch_kernels && KH == 3 && KW == 3 && stride == 2 && C == 32 && F == 64 && g.OW <= 31 && IW <= 64 &&
+      (xact == nullptr || xact_bits)) {
+    // dz rows staged once in LDS, all four parity classes computed from there (pconv.h); bit-identical output
+    bool uniform = true;                // the byte mask is given for every group or for none
+    if (xact != nullptr)
+      for (int i = 0; i < ngroups; ++i) uniform = uniform && ((xact[i] != nullptr) == (xact[0] != nullptr));
+    if (uniform) {
+      PConvDgradArgs a;
+      a.B = B; a.IH = IH; a.IW = IW; a.OH = g.OH; a.OW = g.OW;
+      a.nbands = cdiv((IH + 1) / 2, PDgradCfg::P);
+      a.d_bands = make_fastdiv(a.nbands);
+      for (int i = 0; i < ngroups; ++i) {
+        a.dz[i] = (const ushort_t*)dz[i]; a.wd[i] = (const ushort_t*)wd[i]; a.dx[i] = (ushort_t*)dx[i];
+        a.xbits[i] = xact ? (const unsigned char*)xact[i] : nullptr;
+      }
+      return pconv_dgrad_launch(a, ngroups, (hipStream_t)stream, "convs_dgrad(patch)");
+    }
+  }
   ConvDgradS p; p.g = g; p.G = ngroups; p.xact_bits = xact_bits;
   p.d_f_ = make_fastdiv(g.F);
   for (int ci = 0; ci < stride * stride; ++ci) {

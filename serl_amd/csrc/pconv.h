@@ -22,6 +22,7 @@
 // per step, loading fragments straight from the [F][2][K] layout made every lane fetch its own cache line: both measured
 // slower than the im2col kernel.)
 #pragma once
+#include <stdlib.h>
 #include "conv_geom.h"
 #include "sgemm.h"
 
@@ -283,10 +284,279 @@ static int pconv_fwd_launch(const PConvFwdArgs& a, int ngroups, hipStream_t st, 
     opted[dev] = true;
   }
   const int nitems = a.B * a.nbands;
+  static int items_per_block = -1;
+  if (items_per_block < 0) {
+    const char* e = getenv("SERL_PCONV_ITEMS");
+    items_per_block = e ? atoi(e) : 0;
+  }
   int gx = (ncu[dev] > 0 ? ncu[dev] : 256) / ngroups;
+  if (items_per_block > 0) gx = cdiv(nitems, items_per_block);
   if (gx < 1) gx = 1;
   if (gx > nitems) gx = nitems;
   hipLaunchKernelGGL((pconv_fwd_kernel<G>), dim3(gx, 1, ngroups), dim3(G::NT), G::LDS, st, a);
+  SERL_CHECK_LAUNCH(name);
+  return SERL_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ data gradient
+// dx = conv_transpose(dz, w) for a 3x3 stride-2 layer with C = 32, F = 64, masked by the ReLU byte mask of x.
+// Per parity class (py, px) of input pixels the taps with ky = py (mod 2), kx = px (mod 2) contribute:
+//   dx[2 iyp + py][2 ixp + px][c] = sum_{jy, jx, f} dz[iyp - jy][ixp - jx][f] * w[py + 2 jy][px + 2 jx][c][f]
+// (4 / 2 / 2 / 1 taps), the same k order (jy, jx, f) as sgemm_kernel<ConvDgradS>: bit-identical output.
+// The im2col kernel runs the four classes as separate GEMMs that each gather dz from global memory (measured 1.65x
+// the algorithmic bytes).  Here an item is a band of P = 4 input row PAIRS of one image: its P + 1 rows of dz are
+// staged once in LDS by LDS-DMA (double-buffered; record 31 of every row and the rows outside the image are zeros, so
+// out-of-range taps need no predicate) and all four classes read their A fragments from that patch.
+// 8 waves: wave 2p handles class (0,0) of row pair p (16 k16 steps), wave 2p+1 classes (0,1), (1,0), (1,1) (8 + 8 + 4):
+// each keeps exactly its classes' weight fragments in registers (128 / 160 VGPRs).  The output leaves through a
+// wave-private fp32 tile in LDS, so an item needs one workgroup barrier.
+struct PConvDgradArgs {
+  const unsigned short* dz[MAXG];
+  const unsigned short* wd[MAXG];     // S format [(ky, kx, c)][2][F]
+  const unsigned char* xbits[MAXG];   // byte mask [B*IH*IW][C/8] or nullptr
+  unsigned short* dx[MAXG];
+  int B, IH, IW, OH, OW, nbands;
+  FastDiv d_bands;
+};
+
+__device__ uint4 g_pconv_dump[320];     // stores of lanes that hold no valid pixel land here (never read)
+
+struct PDgradCfg {
+  static constexpr int C = 32, F = 64, P = 4, NT = 512;
+  static constexpr int REC = 4 * F, NCH = F / 4;          // 256-byte records, 16 chunks
+  static constexpr int ROWB = 32 * REC;
+  static constexpr int PATCH = (P + 1) * ROWB;
+  static constexpr int SLOTS = PATCH / 16, NDMA = SLOTS / NT;
+  static constexpr int CSLD = C + 4, CSB = 32 * CSLD * 4;  // wave-private output tile
+  static constexpr int MSB = 2 * P * 64 * (C / 8);        // mask bytes of one item: 2P rows x (IW <= 64) pixels x C/8
+  static constexpr int LDS = 2 * PATCH + 8 * CSB + 2 * MSB;
+  static_assert(SLOTS % NT == 0 && MSB == 8 * 256 && LDS <= 160 * 1024, "LDS");
+};
+
+// K loop of one 32-pixel tile of class (PY, PX): row pair iyl of the band, B fragments bh/bl[t * 4 + kc]
+template <int PY, int PX>
+__device__ __forceinline__ void pdgrad_tile(const unsigned char* patch, int iyl, int r, int h, const bf16x8_t* bh,
+                                            const bf16x8_t* bl, f32x16& acc) {
+  constexpr int TY = PY ? 1 : 2, TX = PX ? 1 : 2;
+  constexpr int ROWB = PDgradCfg::ROWB;
+#pragma unroll
+  for (int jy = 0; jy < TY; ++jy)
+#pragma unroll
+    for (int jx = 0; jx < TX; ++jx) {
+      const int t = jy * TX + jx;
+      const int rec = (r - jx) & 31;
+      const unsigned char* base = patch + (iyl - jy + 1) * ROWB + rec * 256;
+      const int sw = (rec & 15) << 4;
+#pragma unroll
+      for (int kc = 0; kc < 4; ++kc) {
+        const bf16x8_t ah = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(base + (((kc * 2 + h) << 4) ^ sw)));
+        const bf16x8_t al = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(base + (((kc * 2 + h + 8) << 4) ^ sw)));
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[t * 4 + kc], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[t * 4 + kc], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[t * 4 + kc], acc, 0, 0, 0);
+      }
+    }
+}
+
+// B fragments of class (PY, PX): lane (r = c, h) holds f = 16 kc + 8 h .. + 7 of tap t
+template <int PY, int PX>
+__device__ __forceinline__ void pdgrad_load_b(const unsigned short* wd, int r, int h, bf16x8_t* bh, bf16x8_t* bl) {
+  constexpr int TY = PY ? 1 : 2, TX = PX ? 1 : 2, C = PDgradCfg::C, F = PDgradCfg::F;
+#pragma unroll
+  for (int jy = 0; jy < TY; ++jy)
+#pragma unroll
+    for (int jx = 0; jx < TX; ++jx) {
+      const int tap = (PY + 2 * jy) * 3 + (PX + 2 * jx);
+      const unsigned short* row = wd + (size_t)((tap * C + r) * 2) * F + h * 8;
+#pragma unroll
+      for (int kc = 0; kc < 4; ++kc) {
+        bh[(jy * TX + jx) * 4 + kc] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(row + kc * 16));
+        bl[(jy * TX + jx) * 4 + kc] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(row + F + kc * 16));
+      }
+    }
+}
+
+// One tile out: accumulators -> wave-private fp32 tile -> per lane two (pixel, 8-channel) units: ReLU byte mask (from
+// the mask bytes the DMA brought into LDS at ms_base, or none), hi / lo split, two 16-byte stores.  Lanes whose pixel is
+// outside the image store to g_pconv_dump, so that every wave issues the same number of stores per item.
+// LDS reads by hand: hipcc puts vmcnt(0) in front of an LDS read it cannot tell apart from an LDS-DMA destination (and
+// in front of the use of any ordinary global load while a DMA is in flight), which would wait for the NEXT item's patch.
+template <int PY, int PX>
+__device__ __forceinline__ void pdgrad_store(const PConvDgradArgs& a, int z, int b, int band, int iyl, float* Cs,
+                                             uint32_t cs_base, uint32_t ms_base, bool masked, const f32x16& acc, int lane) {
+  constexpr int C = PDgradCfg::C, LD = PDgradCfg::CSLD, P = PDgradCfg::P;
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) Cs[((q & 3) + 8 * (q >> 2) + 4 * h) * LD + r] = acc[q];
+  const int iy = 2 * (band * P + iyl) + PY;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int u = lane + 64 * pass, pxl = u >> 2, ch = u & 3;
+    const int ix = 2 * pxl + PX;
+    const bool ok = iy < a.IH && ix < a.IW;
+    u32x4_t c0, c1;
+    uint32_t bits = 0xffu;
+    if (masked) {
+      const uint32_t maddr = ms_base + (ok ? (uint32_t)(((2 * iyl + PY) * a.IW + ix) * (C >> 3) + ch) : 0u);
+      asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:16\n\tds_read_u8 %2, %4\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&v"(c0), "=&v"(c1), "=&v"(bits) : "v"(cs_base + (uint32_t)(pxl * LD + ch * 8) * 4u), "v"(maddr) : "memory");
+    } else {
+      asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&v"(c0), "=&v"(c1) : "v"(cs_base + (uint32_t)(pxl * LD + ch * 8) * 4u) : "memory");
+    }
+    float v[8] = {__uint_as_float(c0[0]), __uint_as_float(c0[1]), __uint_as_float(c0[2]), __uint_as_float(c0[3]),
+                  __uint_as_float(c1[0]), __uint_as_float(c1[1]), __uint_as_float(c1[2]), __uint_as_float(c1[3])};
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (!(bits & (1u << j))) v[j] = 0.f;
+    u32x4_t hi, lo;
+    uint32_t hh, ll;
+    split_pair(v[0], v[1], hh, ll); hi[0] = hh; lo[0] = ll;
+    split_pair(v[2], v[3], hh, ll); hi[1] = hh; lo[1] = ll;
+    split_pair(v[4], v[5], hh, ll); hi[2] = hh; lo[2] = ll;
+    split_pair(v[6], v[7], hh, ll); hi[3] = hh; lo[3] = ll;
+    unsigned short* dst = ok ? a.dx[z] + ((size_t)(b * a.IH + iy) * a.IW + ix) * 2 * C + ch * 8
+                             : reinterpret_cast<unsigned short*>(g_pconv_dump) + lane * 32;
+    *reinterpret_cast<u32x4_t*>(dst) = hi;
+    *reinterpret_cast<u32x4_t*>(dst + C) = lo;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the tile is reused by this wave's next class
+}
+
+__global__ __launch_bounds__(512, 1) void pconv_dgrad_kernel(const PConvDgradArgs a) {
+  typedef PDgradCfg G;
+  constexpr int P = G::P, NT = G::NT, ROWB = G::ROWB, NDMA = G::NDMA;
+  extern __shared__ __attribute__((aligned(16))) unsigned char p_smem[];
+  const int z = blockIdx.z;
+  const int nitems = a.B * a.nbands;
+  const int per = (nitems + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int it0 = blockIdx.x * per, it1 = min(nitems, it0 + per);
+  if (it0 >= it1) return;
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int iyl = wid >> 1;                 // row pair of the band
+  const bool type_x = (wid & 1) == 0;       // class (0,0) | classes (0,1), (1,0), (1,1)
+  float* const Cs = reinterpret_cast<float*>(p_smem + 2 * G::PATCH + wid * G::CSB);
+  const uint32_t cs_base = (uint32_t)(size_t)(pconv_lptr_t)Cs;
+
+  unsigned char* const Ms = p_smem + 2 * G::PATCH + 8 * G::CSB;          // [2][MSB] mask bytes of the item's 2P rows
+  const uint32_t ms_base0 = (uint32_t)(size_t)(pconv_lptr_t)Ms;
+  const bool masked = a.xbits[z] != nullptr;
+
+  struct DmaSrc { const char* dz; const char* mk; int oy_first, mk_bytes; };
+  auto dma_src = [&](int item) {
+    const int b = (int)fd_div((uint32_t)item, a.d_bands), band = item - b * a.nbands;
+    DmaSrc d;
+    d.oy_first = band * P - 1;              // dz row of patch row 0
+    d.dz = reinterpret_cast<const char*>(a.dz[z]) + (size_t)b * a.OH * a.OW * G::REC;
+    // the mask bytes of input rows 2P*band .. + 2P - 1 are one contiguous span
+    d.mk = reinterpret_cast<const char*>(a.xbits[z]) + ((size_t)(b * a.IH + 2 * P * band) * a.IW) * (G::C / 8);
+    d.mk_bytes = max(0, min(2 * P, a.IH - 2 * P * band)) * a.IW * (G::C / 8);
+    return d;
+  };
+  auto dma_mask = [&](const DmaSrc& d, int buf) {           // wave w brings bytes [256 w, 256 w + 256) of the span
+    if (!masked) return;
+    const int off = wid * 256 + lane * 4;
+    const char* g = off < d.mk_bytes ? d.mk + off : reinterpret_cast<const char*>(g_zero_page);
+    __builtin_amdgcn_global_load_lds((pconv_gptr_t)g, (pconv_lptr_t)(Ms + buf * G::MSB + wid * 256), 4, 0, 0);
+  };
+  auto dma_piece = [&](const DmaSrc& d, unsigned char* patch, int i) {
+    const int l = (i * 8 + wid) * 64 + lane;
+    const int rec = l >> 4, chp = l & 15;
+    const int row = rec >> 5, ox = rec & 31, oy = d.oy_first + row;
+    const bool ok = oy >= 0 && oy < a.OH && ox < a.OW;
+    const char* g = ok ? d.dz + (size_t)(((oy * a.OW + ox) << 4) + (chp ^ (ox & 15))) * 16
+                       : reinterpret_cast<const char*>(g_zero_page);
+    __builtin_amdgcn_global_load_lds((pconv_gptr_t)g, (pconv_lptr_t)(patch + (i * 8 + wid) * 1024), 16, 0, 0);
+  };
+  {
+    const DmaSrc d0 = dma_src(it0);
+#pragma unroll 1
+    for (int i = 0; i < NDMA; ++i) dma_piece(d0, p_smem, i);
+    dma_mask(d0, 0);
+  }
+
+  if (type_x) {
+    bf16x8_t bh[16], bl[16];
+    pdgrad_load_b<0, 0>(a.wd[z], r, h, bh, bl);
+    int pb = 0;
+    for (int item = it0; item < it1; ++item, pb ^= 1) {
+      const unsigned char* patch = p_smem + pb * G::PATCH;
+      unsigned char* npatch = p_smem + (pb ^ 1) * G::PATCH;
+      const int b = (int)fd_div((uint32_t)item, a.d_bands), band = item - b * a.nbands;
+      // this item's patch has landed; the stores of the previous item (4 per wave of this type) are younger than its
+      // DMA and vmcnt retires in order, so they stay in flight
+      if (item == it0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      const bool more = item + 1 < it1;
+      const DmaSrc dn = dma_src(more ? item + 1 : item);
+      if (more) {
+#pragma unroll
+        for (int i = 0; i < NDMA; ++i) dma_piece(dn, npatch, i);
+        dma_mask(dn, pb ^ 1);
+      }
+      const uint32_t ms_base = ms_base0 + pb * G::MSB;
+      f32x16 acc;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+      pdgrad_tile<0, 0>(patch, iyl, r, h, bh, bl, acc);
+      pdgrad_store<0, 0>(a, z, b, band, iyl, Cs, cs_base, ms_base, masked, acc, lane);
+    }
+  } else {
+    bf16x8_t bh[20], bl[20];
+    pdgrad_load_b<0, 1>(a.wd[z], r, h, bh, bl);
+    pdgrad_load_b<1, 0>(a.wd[z], r, h, bh + 8, bl + 8);
+    pdgrad_load_b<1, 1>(a.wd[z], r, h, bh + 16, bl + 16);
+    int pb = 0;
+    for (int item = it0; item < it1; ++item, pb ^= 1) {
+      const unsigned char* patch = p_smem + pb * G::PATCH;
+      unsigned char* npatch = p_smem + (pb ^ 1) * G::PATCH;
+      const int b = (int)fd_div((uint32_t)item, a.d_bands), band = item - b * a.nbands;
+      if (item == it0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");      // 3 classes x 4 stores
+      __builtin_amdgcn_s_barrier();
+      const bool more = item + 1 < it1;
+      const DmaSrc dn = dma_src(more ? item + 1 : item);
+      if (more) {
+#pragma unroll
+        for (int i = 0; i < NDMA; ++i) dma_piece(dn, npatch, i);
+        dma_mask(dn, pb ^ 1);
+      }
+      const uint32_t ms_base = ms_base0 + pb * G::MSB;
+      f32x16 acc;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+      pdgrad_tile<0, 1>(patch, iyl, r, h, bh, bl, acc);
+      pdgrad_store<0, 1>(a, z, b, band, iyl, Cs, cs_base, ms_base, masked, acc, lane);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+      pdgrad_tile<1, 0>(patch, iyl, r, h, bh + 8, bl + 8, acc);
+      pdgrad_store<1, 0>(a, z, b, band, iyl, Cs, cs_base, ms_base, masked, acc, lane);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+      pdgrad_tile<1, 1>(patch, iyl, r, h, bh + 16, bl + 16, acc);
+      pdgrad_store<1, 1>(a, z, b, band, iyl, Cs, cs_base, ms_base, masked, acc, lane);
+    }
+  }
+}
+
+static int pconv_dgrad_launch(const PConvDgradArgs& a, int ngroups, hipStream_t st, const char* name) {
+  static bool opted[64] = {};
+  static int ncu[64] = {};
+  int dev = 0;
+  SERL_CHECK_HIP(hipGetDevice(&dev), name);
+  SERL_CHECK_ARG(dev >= 0 && dev < 64, "%s: device ordinal %d out of range", name, dev);
+  if (!opted[dev]) {
+    SERL_CHECK_HIP(hipFuncSetAttribute((const void*)pconv_dgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PDgradCfg::LDS), name);
+    SERL_CHECK_HIP(hipDeviceGetAttribute(&ncu[dev], hipDeviceAttributeMultiprocessorCount, dev), name);
+    opted[dev] = true;
+  }
+  const int nitems = a.B * a.nbands;
+  int gx = (ncu[dev] > 0 ? ncu[dev] : 256) / ngroups;
+  if (gx < 1) gx = 1;
+  if (gx > nitems) gx = nitems;
+  hipLaunchKernelGGL(pconv_dgrad_kernel, dim3(gx, 1, ngroups), dim3(PDgradCfg::NT), PDgradCfg::LDS, st, a);
   SERL_CHECK_LAUNCH(name);
   return SERL_OK;
 }

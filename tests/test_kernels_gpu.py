@@ -267,14 +267,18 @@ def test_patch_conv_bit_identical_to_im2col(dev, case):
                           rmasks=[rm[0].data_ptr(), 0, rm[2].data_ptr()])
             ops.convs_dgrad([t.data_ptr() for t in dzs], [t.data_ptr() for t in wds], [t.data_ptr() for t in xm],
                             [t.data_ptr() for t in dxs], B, IH, IW, Cin, K, K, S, F, st, xact_bits=True)
+            dxn = [torch.full((B * IH * IW * Cin * 2,), -1, dtype=torch.int16, device=dev) for _ in range(G)]
+            ops.convs_dgrad([t.data_ptr() for t in dzs], [t.data_ptr() for t in wds], [0] * G,
+                            [t.data_ptr() for t in dxn], B, IH, IW, Cin, K, K, S, F, st)          # no ReLU mask
             torch.cuda.synchronize()
-            out[mode] = (ys, rm, dxs)
+            out[mode] = (ys, rm, dxs, dxn)
     finally:
         ops.convs_set_patch_kernels(1)
     for g in range(G):
         assert torch.equal(out[0][0][g], out[1][0][g]), f"forward differs, group {g}"
         assert torch.equal(out[0][1][g], out[1][1][g]), f"ReLU byte mask differs, group {g}"
         assert torch.equal(out[0][2][g], out[1][2][g]), f"data gradient differs, group {g}"
+        assert torch.equal(out[0][3][g], out[1][3][g]), f"unmasked data gradient differs, group {g}"
     assert bool((out[1][1][1] == 0xAA).all()), "a NULL mask entry must not be written"
 
 
