@@ -71,6 +71,15 @@ int serl_convs_fwd(int ngroups, const void* const* x, const void* const* wf, con
  * measurements and the bit-identity test of the two paths.  Process-wide; no counterpart in the reference (XLA picks
  * its convolution algorithm itself, two_d4pg_encoder.py:30-38). */
 int serl_convs_set_patch_kernels(int enable);
+/* Layers 1 + 2 of a NO-GRADIENT encoder pass (target critic, actor: two_d4pg_encoder.py:30-38 under stop_gradient /
+ * in the target network) in one launch: uint8 frames [B][IH1][IW1][C1] -> 3x3 stride-2 conv (-> F1 = 32) + bias + ReLU ->
+ * 3x3 stride-2 conv (-> F2 = 64) + bias [+ ReLU] -> y (S format); wf1 / wf2 as serl_convs_prep_weights writes them
+ * (in_u8 = 1 / 0).  Layer 1's output is never written to memory.  Bit-identical to the two serl_convs_fwd calls.
+ * serl_convs_fwd12_supported returns 1 when the geometry fits the kernel (else serl_convs_fwd12 returns status 1). */
+int serl_convs_fwd12_supported(int IH1, int IW1, int C1, int F1, int F2);
+int serl_convs_fwd12(int ngroups, const void* const* x_u8, const void* const* wf1, const float* const* bias1,
+                     const void* const* wf2, const float* const* bias2, void* const* y, int B, int IH1, int IW1, int C1,
+                     int F1, int F2, int relu, void* const* rmask, void* stream);
 int serl_convs_dgrad(int ngroups, const void* const* dz, const void* const* wd, const void* const* xact,
                      void* const* dx, int B, int IH, int IW, int C, int KH, int KW, int stride, int F, int xact_bits,
                      void* stream);

@@ -542,7 +542,7 @@ extern "C" int serl_convs_prep_weights(int ngroups, const float* const* w, void*
                                        int KH, int KW, int C, int F, void* stream) {
   SERL_CHECK_ARG(ngroups >= 1 && ngroups <= MAXG, "convs_prep_weights: ngroups must be in [1,%d]", MAXG);
   SERL_CHECK_ARG(KH > 0 && KW > 0 && C > 0 && F > 0 && F % 8 == 0, "convs_prep_weights: F must be a multiple of 8");
-  SERL_CHECK_ARG(in_u8 ? KW * C <= 32 : C % 8 == 0, "convs_prep_weights: need C %% 8 == 0 (or KW*C <= 32 for uint8 input)");
+  SERL_CHECK_ARG(in_u8 ? (KW * C >= 8 && KW * C <= 32) : C % 8 == 0, "convs_prep_weights: need C %% 8 == 0 (or 8 <= KW*C <= 32 for uint8 input)");
   PrepArgs a;
   a.KH = KH; a.KWC = KW * C; a.F = F; a.Kp = s_kp(in_u8, KH, KW, C); a.pad32 = in_u8;
   for (int i = 0; i < ngroups; ++i) {
@@ -563,8 +563,8 @@ extern "C" int serl_convs_prep_weights_multi(int njobs, const float* const* w, v
   int gx = 0, gy = 0;
   for (int i = 0; i < njobs; ++i) {
     SERL_CHECK_ARG(KH[i] > 0 && KW[i] > 0 && C[i] > 0 && F[i] > 0 && F[i] % 8 == 0, "convs_prep_weights_multi: F must be a multiple of 8");
-    SERL_CHECK_ARG(in_u8[i] ? KW[i] * C[i] <= 32 : C[i] % 8 == 0,
-                   "convs_prep_weights_multi: need C %% 8 == 0 (or KW*C <= 32 for uint8 input)");
+    SERL_CHECK_ARG(in_u8[i] ? (KW[i] * C[i] >= 8 && KW[i] * C[i] <= 32) : C[i] % 8 == 0,
+                   "convs_prep_weights_multi: need C %% 8 == 0 (or 8 <= KW*C <= 32 for uint8 input)");
     SERL_CHECK_ARG(w[i] && wf[i], "convs_prep_weights_multi: null pointer");
     a.w[i] = w[i]; a.wf[i] = (ushort_t*)wf[i]; a.wd[i] = wd ? (ushort_t*)wd[i] : nullptr;
     a.KH[i] = KH[i]; a.KWC[i] = KW[i] * C[i]; a.F[i] = F[i]; a.Kp[i] = s_kp(in_u8[i], KH[i], KW[i], C[i]); a.pad32[i] = in_u8[i];
@@ -589,7 +589,7 @@ extern "C" int serl_convs_fwd(int ngroups, const void* const* x, const void* con
   SERL_CHECK_ARG(ngroups >= 1 && ngroups <= MAXG, "convs_fwd: ngroups must be in [1,%d]", MAXG);
   ConvGeom g;
   if (int e = make_geom(g, B, IH, IW, C, KH, KW, stride, F)) return e;
-  SERL_CHECK_ARG(F % 8 == 0 && (in_u8 ? KW * C <= 32 : C % 8 == 0), "convs_fwd: need F %% 8 == 0 and C %% 8 == 0 (uint8 input: KW*C <= 32)");
+  SERL_CHECK_ARG(F % 8 == 0 && (in_u8 ? (KW * C >= 8 && KW * C <= 32) : C % 8 == 0), "convs_fwd: need F %% 8 == 0 and C %% 8 == 0 (uint8 input: 8 <= KW*C <= 32)");
   SERL_CHECK_ARG(all_aligned16(wf, ngroups) && all_aligned16(y, ngroups) && (in_u8 || all_aligned16(x, ngroups)),
                  "convs_fwd: S-format tensors must be 16-byte aligned");
   const int M = B * g.OH * g.OW;
@@ -622,6 +622,45 @@ extern "C" int serl_convs_fwd(int ngroups, const void* const* x, const void* con
   if (in_u8) { ConvFwdS<true> p; FILL(p) return s_launch_by_n(S_FWD, p, M, F, 1, ngroups, st, "convs_fwd_u8"); }
   ConvFwdS<false> p; FILL(p) return s_launch_by_n(S_FWD, p, M, F, 1, ngroups, st, "convs_fwd");
 #undef FILL
+}
+
+// Layers 1 + 2 of a no-gradient encoder pass in one launch (pconv.h, pconv_fused12_kernel): uint8 frames -> 3x3/2 conv
+// (-> 32) + bias + ReLU -> 3x3/2 conv (-> 64) + bias [+ ReLU]; layer 1's output never reaches HBM.  Bit-identical to
+// serl_convs_fwd(in_u8 = 1) followed by serl_convs_fwd.  serl_convs_fwd12_supported says whether a geometry fits.
+static bool fused12_fits(int IH1, int IW1, int C1, int F1, int F2) {
+  if (IH1 < 7 || IW1 < 7 || 3 * C1 < 8 || 3 * C1 > 32 || F1 != 32 || F2 != 64) return false;   // (uint8 runs of 8..32 bytes, as serl_convs_fwd)
+  const int rb1 = IW1 * C1;
+  if (rb1 % 16 != 0 || rb1 > PFusedCfg::RB1MAX) return false;
+  const int IW = (IW1 - 3) / 2 + 1, OW = (IW - 3) / 2 + 1;
+  return IW <= 64 && OW <= 32 && (IW + 1) / 2 <= 32;
+}
+extern "C" int serl_convs_fwd12_supported(int IH1, int IW1, int C1, int F1, int F2) {
+  return fused12_fits(IH1, IW1, C1, F1, F2) ? 1 : 0;
+}
+extern "C" int serl_convs_fwd12(int ngroups, const void* const* x_u8, const void* const* wf1, const float* const* bias1,
+                                const void* const* wf2, const float* const* bias2, void* const* y, int B, int IH1,
+                                int IW1, int C1, int F1, int F2, int relu, void* const* rmask, void* stream) {
+  SERL_CHECK_ARG(ngroups >= 1 && ngroups <= MAXG, "convs_fwd12: ngroups must be in [1,%d]", MAXG);
+  SERL_CHECK_ARG(B > 0 && fused12_fits(IH1, IW1, C1, F1, F2),
+                 "convs_fwd12: geometry %dx%dx%d -> %d -> %d does not fit the fused kernel (serl_convs_fwd12_supported)",
+                 IH1, IW1, C1, F1, F2);
+  SERL_CHECK_ARG((long long)B * IH1 * IW1 * C1 < (1ll << 31), "convs_fwd12: tensor exceeds 2^31 elements");
+  SERL_CHECK_ARG(all_aligned16(x_u8, ngroups) && all_aligned16(wf1, ngroups) && all_aligned16(wf2, ngroups) &&
+                 all_aligned16(y, ngroups), "convs_fwd12: frames, weights and output must be 16-byte aligned");
+  PConvFusedArgs a;
+  a.B = B; a.IH1 = IH1; a.IW1 = IW1; a.C1 = C1; a.relu = relu;
+  const int IH = (IH1 - 3) / 2 + 1;
+  a.IW = (IW1 - 3) / 2 + 1;
+  a.OH = (IH - 3) / 2 + 1; a.OW = (a.IW - 3) / 2 + 1;
+  a.nbands = cdiv(a.OH, PFusedCfg::R);
+  a.d_bands = make_fastdiv(a.nbands);
+  for (int i = 0; i < ngroups; ++i) {
+    SERL_CHECK_ARG(bias1[i] && bias2[i], "convs_fwd12: null bias");
+    a.u8[i] = (const unsigned char*)x_u8[i]; a.wf1[i] = (const ushort_t*)wf1[i]; a.bias1[i] = bias1[i];
+    a.wf2[i] = (const ushort_t*)wf2[i]; a.bias2[i] = bias2[i]; a.y[i] = (ushort_t*)y[i];
+    a.rmask[i] = rmask ? (unsigned char*)rmask[i] : nullptr;
+  }
+  return pconv_fused12_launch(a, ngroups, (hipStream_t)stream, "convs_fwd12");
 }
 
 extern "C" int serl_convs_dgrad(int ngroups, const void* const* dz, const void* const* wd, const void* const* xact,
@@ -680,7 +719,7 @@ static int convs_wgrad_impl(const char* name, int ngroups, const void* const* x,
   SERL_CHECK_ARG(ngroups >= 1 && ngroups <= MAXG, "%s: ngroups must be in [1,%d]", name, MAXG);
   ConvGeom g;
   if (int e = make_geom(g, B, IH, IW, C, KH, KW, stride, F)) return e;
-  SERL_CHECK_ARG(F % 8 == 0 && (in_u8 ? KW * C <= 32 : C % 8 == 0), "%s: need F %% 8 == 0 and C %% 8 == 0 (uint8 input: KW*C <= 32)", name);
+  SERL_CHECK_ARG(F % 8 == 0 && (in_u8 ? (KW * C >= 8 && KW * C <= 32) : C % 8 == 0), "%s: need F %% 8 == 0 and C %% 8 == 0 (uint8 input: 8 <= KW*C <= 32)", name);
   SERL_CHECK_ARG(all_aligned16(dz, ngroups) && (in_u8 || all_aligned16(x, ngroups)), "%s: S-format tensors must be 16-byte aligned", name);
   int nsplit, klen;
   wgrad_plan(g, ngroups, nsplit, klen);

@@ -560,3 +560,274 @@ static int pconv_dgrad_launch(const PConvDgradArgs& a, int ngroups, hipStream_t 
   SERL_CHECK_LAUNCH(name);
   return SERL_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ conv1 + conv2 fused
+// The first two layers of a NO-GRADIENT encoder pass (target critic, actor) in one kernel: uint8 frames -> conv 3x3/2
+// (C1 <= 10 -> 32) + bias + ReLU -> conv 3x3/2 (32 -> 64) + bias + ReLU.  The first layer's output (508 KB per 128 x 128
+// image in S format, the largest tensor of the encoder) is never written to HBM: per item (R = 4 output rows of one
+// image) the block DMA-copies the 4R + 3 uint8 rows it needs (22 KB), computes the 2R + 1 rows of layer-1 output it
+// needs on the matrix cores and writes them, rounded to S format exactly as serl_convs_fwd would store them, into the
+// same LDS patch the stand-alone kernel fills by DMA; the second layer's K loop and output path are that kernel's.
+// Same k order and MFMA sequence as the two im2col launches (uint8 layer: k' = ky * 32 + kx * C1 + c, products
+// a_hi * b_lo + a_hi * b_hi; the bytes past a row's run meet zero weights): bit-identical to running them one after
+// the other.  Layer-1 halo rows are computed twice (9/8 of the layer-1 work).
+struct PConvFusedArgs {
+  const unsigned char* u8[MAXG];      // [B][IH1][IW1][C1]
+  const unsigned short* wf1[MAXG];    // S format [32][2][KH * 32]
+  const float* bias1[MAXG];
+  const unsigned short* wf2[MAXG];    // S format [64][2][288]
+  const float* bias2[MAXG];
+  unsigned short* y[MAXG];            // layer-2 output, S format [B][OH][OW][64]
+  unsigned char* rmask[MAXG];
+  int B, IH1, IW1, C1, IW, OH, OW, nbands, relu;     // IW: layer-1 output width = layer-2 input width
+  FastDiv d_bands;
+};
+
+struct PFusedCfg {
+  typedef PFwdCfg<32, 64, 4, 32> G2;
+  static constexpr int NT = 512, R = 4;
+  static constexpr int U8ROWS = 4 * R + 3;               // uint8 rows per item
+  static constexpr int RB1MAX = 1152;                    // bytes per uint8 row (IW1 * C1), multiple of 16
+  static constexpr int U8BUF = 3 * NT * 16;              // 24 KB >= U8ROWS * RB1MAX + slack, 3 DMA pieces per thread
+  static constexpr int W1IMG = 6 * 2 * 32 * 32;          // layer-1 weights as B fragments: [k16 step][plane][f][2 x 16 B]
+  static constexpr int LDS = G2::PATCH + 2 * U8BUF + W1IMG;
+  static_assert(U8ROWS * RB1MAX + 64 <= U8BUF && LDS <= 160 * 1024, "LDS");
+};
+
+__global__ __launch_bounds__(512, 1) void pconv_fused12_kernel(const PConvFusedArgs a) {
+  typedef PFusedCfg::G2 G;
+  constexpr int C = G::C, F = G::F, R = G::R, OWP = G::OWP, NT = G::NT;
+  constexpr int REC = G::REC, ROWB = G::ROWB, PARB = OWP * REC;
+  constexpr int KS = C / 16, NS = 9 * KS;
+  constexpr int Kp = G::KP, WROW = G::WROW;
+  constexpr int U8BUF = PFusedCfg::U8BUF;
+  extern __shared__ __attribute__((aligned(16))) unsigned char p_smem[];
+  unsigned char* const patch = p_smem;                       // layer-1 output of the item (S format, swizzled image)
+  unsigned char* const u8buf = p_smem + G::PATCH;            // [2][U8BUF]
+
+  const int z = blockIdx.z;
+  const int nitems = a.B * a.nbands;
+  const int per = (nitems + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int it0 = blockIdx.x * per, it1 = min(nitems, it0 + per);
+  if (it0 >= it1) return;
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int wm = wid / G::NTL, wn = wid - wm * G::NTL;
+  const int RB1 = a.IW1 * a.C1;
+
+  // ---- layer-2 weights -> fragments in registers (as pconv_fwd_kernel), layer-1 weights straight from global memory
+  bf16x8_t rbh[NS], rbl[NS];
+  {
+    constexpr int CPR = Kp / 8;
+    constexpr int NWC = 2 * F * CPR, NWL = (NWC + NT - 1) / NT;
+    const char* wsrc = reinterpret_cast<const char*>(a.wf2[z]);
+    u32x4_t wv[NWL];
+#pragma unroll
+    for (int i = 0; i < NWL; ++i) {
+      const int q = tid + i * NT;
+      wv[i] = *reinterpret_cast<const u32x4_t*>(q < NWC ? wsrc + (size_t)q * 16 : reinterpret_cast<const char*>(g_zero_page));
+    }
+#pragma unroll
+    for (int i = 0; i < NWL; ++i) {
+      const int q = tid + i * NT;
+      if (q < NWC) {
+        const int row = q / CPR, kc = q - row * CPR;
+        *reinterpret_cast<u32x4_t*>(p_smem + ((row & 1) * F + (row >> 1)) * WROW + kc * 16) = wv[i];
+      }
+    }
+    __syncthreads();
+    const unsigned char* wrow = p_smem + (wn * 32 + r) * WROW + h * 16;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      rbh[s] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(wrow + s * 32));
+      rbl[s] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(wrow + F * WROW + s * 32));
+    }
+  }
+  // layer-1 weights: fragment image in LDS (lane (r = f, h) reads k' = 16 s + 8 h .. + 7; the two halves of a row swap
+  // on odd 8-row groups so that a 16-lane group of ds_read_b128 covers 16 distinct bank groups)
+  unsigned char* const W1s = p_smem + G::PATCH + 2 * U8BUF;
+  for (int id = tid; id < 6 * 2 * 32 * 2; id += NT) {
+    const int hh = id & 1, f = (id >> 1) & 31, plane = (id >> 6) & 1, s6 = id >> 7;
+    *reinterpret_cast<u32x4_t*>(W1s + ((s6 * 2 + plane) * 32 + f) * 32 + ((hh ^ ((f >> 3) & 1)) << 4)) =
+        *reinterpret_cast<const u32x4_t*>(a.wf1[z] + (size_t)(f * 2 + plane) * 96 + s6 * 16 + hh * 8);
+  }
+  const unsigned char* const w1p = W1s + r * 32 + ((h ^ ((r >> 3) & 1)) << 4);
+  const float b1 = a.bias1[z][r];
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();            // weight image consumed: the LDS is free for the patches
+
+  const int ox = r & (OWP - 1);
+  const int arow = 2 * min(wm, R - 1) * ROWB;
+  const int rec0 = ox * REC, rec1 = (ox + 1) * REC;
+  const int sw0 = pconv_swz<REC>(ox) << 4, sw1 = pconv_swz<REC>(ox + 1) << 4;
+  constexpr int LDC = F + 4;
+  constexpr int CH = F / 8, RPP = NT / CH;
+  const int n = (tid % CH) * 8;
+  float bs[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) bs[j] = a.bias2[z][n + j];
+  unsigned short* const out = a.y[z];
+  unsigned char* const mk = a.rmask[z];
+
+  // uint8 rows 4*oy0 .. 4*oy0 + 4*rows + 2 of image b: one contiguous span, copied linearly
+  auto dma_u8 = [&](int item, unsigned char* dstbuf) {
+    const int b = (int)fd_div((uint32_t)item, a.d_bands), band = item - b * a.nbands;
+    const int oy0 = band * R;
+    const int nbytes = (4 * min(R, a.OH - oy0) + 3) * RB1;
+    const char* src = reinterpret_cast<const char*>(a.u8[z]) + ((size_t)(b * a.IH1 + 4 * oy0)) * RB1;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int off = ((i * 8 + wid) * 64 + lane) * 16;
+      const char* g = off < nbytes ? src + off : reinterpret_cast<const char*>(g_zero_page);
+      __builtin_amdgcn_global_load_lds((pconv_gptr_t)g, (pconv_lptr_t)(dstbuf + (i * 8 + wid) * 1024), 16, 0, 0);
+    }
+  };
+
+  dma_u8(it0, u8buf);
+  int pb = 0;
+  for (int item = it0; item < it1; ++item, pb ^= 1) {
+    const unsigned char* ub = u8buf + pb * U8BUF;
+    const int b = (int)fd_div((uint32_t)item, a.d_bands), band = item - b * a.nbands;
+    const int oy0 = band * R;
+    const int rows_here = min(R, a.OH - oy0);
+    const int nrows1 = 2 * rows_here + 1;                    // layer-1 output rows of this item
+    // uint8 rows landed; previous item's stores stay in flight (counted wait, see pconv_fwd_kernel); every wave is
+    // done with the previous item's output tile, which lives in the patch
+    static_assert(G::MT * 32 / RPP == 2, "store count of the counted wait");
+    if (item == it0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else if (mk != nullptr) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (item + 1 < it1) dma_u8(item + 1, u8buf + (pb ^ 1) * U8BUF);
+
+    // ---- layer 1: 2 x nrows1 tiles of 32 pixels (row y1, columns 32 half .. + 31), round-robin over the 8 waves
+    for (int t = wid; t < 2 * nrows1; t += 8) {
+      const int y1 = t >> 1, ox1 = (t & 1) * 32 + r;
+      f32x16 acc1;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc1[q] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 6; ++s) {
+        // 8 consecutive bytes (kx, c) of input row 2 y1 + ky at pixel 2 ox1: 2-byte aligned, so three aligned dwords
+        const uint32_t ad = (uint32_t)((2 * y1 + (s >> 1)) * RB1 + 2 * ox1 * a.C1 + (s & 1) * 16 + 8 * h);
+        const uint32_t* p = reinterpret_cast<const uint32_t*>(ub + (ad & ~3u));
+        const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
+        const bool odd = (ad & 2u) != 0;
+        const uint32_t lo4 = odd ? __builtin_amdgcn_alignbyte(d1, d0, 2) : d0;
+        const uint32_t hi4 = odd ? __builtin_amdgcn_alignbyte(d2, d1, 2) : d1;
+        const uint2 e0 = u8x4_to_bf16(lo4), e1 = u8x4_to_bf16(hi4);
+        const u32x4_t av = {e0.x, e0.y, e1.x, e1.y};
+        const bf16x8_t ah = __builtin_bit_cast(bf16x8_t, av);
+        const bf16x8_t w1h = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(w1p + (s * 2) * 1024));
+        const bf16x8_t w1l = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(w1p + (s * 2 + 1) * 1024));
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, w1l, acc1, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, w1h, acc1, 0, 0, 0);
+      }
+      // bias + ReLU + S-format rounding, 2 bytes per (pixel, channel, plane) into the swizzled patch.  Pixel of
+      // accumulator register q: ix = 32 half + 4 h + (q & 3) + 8 (q >> 2), so record j = ix >> 1 and its swizzle
+      // (j >> 1) & 7 = h + 2 (q >> 2) split into a lane part and a compile-time part: one XOR per store.  Columns
+      // past the image (ix = 63, or a narrower layer) go to records no valid lane reads.
+      unsigned char* const tile = patch + y1 * 2 * PARB + ((t & 1) * 16 + 2 * h) * REC + (r & 7) * 2;
+      const int ch0 = ((r >> 3) ^ h) << 4;
+#pragma unroll
+      for (int q = 0; q < 16; q += 2) {
+        const float v0 = fmaxf(fmaf(acc1[q], 1.0f / 255.0f, b1), 0.f), v1 = fmaxf(fmaf(acc1[q + 1], 1.0f / 255.0f, b1), 0.f);
+        uint32_t hh, ll;
+        split_pair(v0, v1, hh, ll);
+        // q even: parity 0, q + 1: parity 1, same j
+        unsigned char* rec = tile + (((q & 3) >> 1) + 4 * (q >> 2)) * REC;
+        const int co = ch0 ^ ((2 * (q >> 2)) << 4);
+        *reinterpret_cast<unsigned short*>(rec + co) = (unsigned short)hh;
+        *reinterpret_cast<unsigned short*>(rec + (co ^ 64)) = (unsigned short)ll;
+        *reinterpret_cast<unsigned short*>(rec + PARB + co) = (unsigned short)(hh >> 16);
+        *reinterpret_cast<unsigned short*>(rec + PARB + (co ^ 64)) = (unsigned short)(ll >> 16);
+      }
+    }
+    pconv_lds_barrier();
+
+    // ---- layer 2 (pconv_fwd_kernel's K loop and output path)
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ky = tap / 3, kx = tap - 3 * ky;
+      const int tapoff = arow + ky * ROWB + (kx & 1) * PARB + (kx == 2 ? rec1 : rec0);
+      const int sw = kx == 2 ? sw1 : sw0;
+#pragma unroll
+      for (int kc = 0; kc < KS; ++kc) {
+        const int chh = ((kc * 2 + h) << 4) ^ sw, chl = ((kc * 2 + h + C / 8) << 4) ^ sw;
+        const bf16x8_t ah = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(patch + tapoff + chh));
+        const bf16x8_t al = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(patch + tapoff + chl));
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, rbh[tap * KS + kc], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, rbl[tap * KS + kc], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, rbh[tap * KS + kc], acc, 0, 0, 0);
+      }
+    }
+    pconv_lds_barrier();
+
+    float* const Cs = reinterpret_cast<float*>(patch);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int row = wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+      Cs[row * LDC + wn * 32 + r] = acc[q];
+    }
+    pconv_lds_barrier();
+    const uint32_t cs_base = (uint32_t)(size_t)(pconv_lptr_t)Cs;
+#pragma unroll
+    for (int pass = 0; pass < G::MT * 32 / RPP; ++pass) {
+      const int row0 = tid / CH + pass * RPP;
+      const int oyl = min(row0 / OWP, rows_here - 1), oxx = min(row0 & (OWP - 1), a.OW - 1);
+      const int row = oyl * OWP + oxx;
+      const size_t pix = (size_t)(b * a.OH + oy0 + oyl) * a.OW + oxx;
+      u32x4_t c0, c1;
+      asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&v"(c0), "=&v"(c1) : "v"(cs_base + (uint32_t)(row * LDC + n) * 4u) : "memory");
+      float v[8] = {__uint_as_float(c0[0]), __uint_as_float(c0[1]), __uint_as_float(c0[2]), __uint_as_float(c0[3]),
+                    __uint_as_float(c1[0]), __uint_as_float(c1[1]), __uint_as_float(c1[2]), __uint_as_float(c1[3])};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        v[j] = fmaf(v[j], 1.0f, bs[j]);
+        if (a.relu) v[j] = fmaxf(v[j], 0.f);
+      }
+      u32x4_t hi, lo;
+      uint32_t hh, ll;
+      split_pair(v[0], v[1], hh, ll); hi[0] = hh; lo[0] = ll;
+      split_pair(v[2], v[3], hh, ll); hi[1] = hh; lo[1] = ll;
+      split_pair(v[4], v[5], hh, ll); hi[2] = hh; lo[2] = ll;
+      split_pair(v[6], v[7], hh, ll); hi[3] = hh; lo[3] = ll;
+      unsigned short* dst = out + pix * 2 * F + n;
+      *reinterpret_cast<u32x4_t*>(dst) = hi;
+      *reinterpret_cast<u32x4_t*>(dst + F) = lo;
+      if (mk != nullptr) {
+        uint32_t bits = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          bits |= (hi[j] & 0x7fffu) ? (1u << (2 * j)) : 0u;
+          bits |= (hi[j] & 0x7fff0000u) ? (2u << (2 * j)) : 0u;
+        }
+        mk[pix * (F >> 3) + (n >> 3)] = (unsigned char)bits;
+      }
+    }
+  }
+}
+
+static int pconv_fused12_launch(const PConvFusedArgs& a, int ngroups, hipStream_t st, const char* name) {
+  static bool opted[64] = {};
+  static int ncu[64] = {};
+  int dev = 0;
+  SERL_CHECK_HIP(hipGetDevice(&dev), name);
+  SERL_CHECK_ARG(dev >= 0 && dev < 64, "%s: device ordinal %d out of range", name, dev);
+  if (!opted[dev]) {
+    SERL_CHECK_HIP(hipFuncSetAttribute((const void*)pconv_fused12_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PFusedCfg::LDS), name);
+    SERL_CHECK_HIP(hipDeviceGetAttribute(&ncu[dev], hipDeviceAttributeMultiprocessorCount, dev), name);
+    opted[dev] = true;
+  }
+  const int nitems = a.B * a.nbands;
+  int gx = (ncu[dev] > 0 ? ncu[dev] : 256) / ngroups;
+  if (gx < 1) gx = 1;
+  if (gx > nitems) gx = nitems;
+  hipLaunchKernelGGL(pconv_fused12_kernel, dim3(gx, 1, ngroups), dim3(PFusedCfg::NT), PFusedCfg::LDS, st, a);
+  SERL_CHECK_LAUNCH(name);
+  return SERL_OK;
+}

@@ -96,6 +96,20 @@ def convs_fwd(xs, wfs, bs, ys, in_u8, B, IH, IW, C, KH, KW, stride, F, relu, str
     call("serl_convs_fwd", n, px, pw, pb, py, int(in_u8), B, IH, IW, C, KH, KW, stride, F, int(relu), pm, stream)
 
 
+def convs_fwd12(xs, wf1s, b1s, wf2s, b2s, ys, B, IH1, IW1, C1, F1, F2, relu, stream, rmasks=None):
+    """Fused layers 1 + 2 of a no-gradient encoder pass (uint8 frames -> S-format layer-2 output)."""
+    n = len(xs)
+    px, kx = ptr_table(xs); p1, k1 = ptr_table(wf1s); pb1, kb1 = ptr_table(b1s); p2, k2 = ptr_table(wf2s)
+    pb2, kb2 = ptr_table(b2s); py, ky = ptr_table(ys)
+    pm, km = ptr_table(rmasks) if rmasks is not None else (None, None)
+    call("serl_convs_fwd12", n, px, p1, pb1, p2, pb2, py, B, IH1, IW1, C1, F1, F2, int(relu), pm, stream)
+
+
+def convs_fwd12_supported(IH1, IW1, C1, F1, F2):
+    from ._lib import load
+    return bool(load().serl_convs_fwd12_supported(IH1, IW1, C1, F1, F2))
+
+
 def convs_set_patch_kernels(enable):
     """Process-wide: 3x3 stride-2 layers on the LDS-patch kernels (default) or on the im2col kernels only."""
     call("serl_convs_set_patch_kernels", int(bool(enable)))

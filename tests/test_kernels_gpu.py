@@ -282,6 +282,53 @@ def test_patch_conv_bit_identical_to_im2col(dev, case):
     assert bool((out[1][1][1] == 0xAA).all()), "a NULL mask entry must not be written"
 
 
+@pytest.mark.parametrize("case", [(3, 128, 128, 9), (2, 100, 128, 9), (2, 128, 128, 3), (2, 31, 32, 8), (1, 7, 16, 3)])
+def test_convs_fwd12_bit_identical_to_two_launches(dev, case):
+    """serl_convs_fwd12 (layers 1 + 2 of a no-gradient pass in one kernel, layer 1's output kept in LDS) against
+    serl_convs_fwd(uint8) followed by serl_convs_fwd: same bits, same ReLU byte mask; full and ragged bands, 1..9 input
+    channels, an image smaller than one band."""
+    ops = _ops()
+    B, IH1, IW1, C1 = case
+    F1, F2, K, S, G = 32, 64, 3, 2, 3
+    assert ops.convs_fwd12_supported(IH1, IW1, C1, F1, F2)
+    assert not ops.convs_fwd12_supported(IH1, IW1, C1, 16, F2) and not ops.convs_fwd12_supported(IH1, IW1 + 1, C1, F1, F2)
+    assert not ops.convs_fwd12_supported(IH1, 16, 2, F1, F2)       # uint8 runs (3 * C1 bytes) shorter than 8 are refused
+    rng = np.random.default_rng(11)
+    st = ops.current_stream()
+    IH, IW = (IH1 - K) // S + 1, (IW1 - K) // S + 1
+    OH, OW = (IH - K) // S + 1, (IW - K) // S + 1
+    wb1, wb2 = ops.convs_weight_bytes(True, K, K, C1, F1), ops.convs_weight_bytes(False, K, K, F1, F2)
+    xs, w1, w2, b1, b2, wf1, wf2 = [], [], [], [], [], [], []
+    for g in range(G):
+        xs.append(dv(rng.integers(0, 256, size=(B, IH1, IW1, C1), dtype=np.uint8), dev))
+        w1.append(dv((rng.standard_normal((K, K, C1, F1)) * 0.3).astype(np.float32), dev))
+        w2.append(dv((rng.standard_normal((K, K, F1, F2)) * 0.1).astype(np.float32), dev))
+        b1.append(dv((rng.standard_normal(F1) * 0.1).astype(np.float32), dev))
+        b2.append(dv((rng.standard_normal(F2) * 0.1).astype(np.float32), dev))
+        wf1.append(torch.full((wb1 // 2,), -1, dtype=torch.int16, device=dev))
+        wf2.append(torch.full((wb2 // 2,), -1, dtype=torch.int16, device=dev))
+    p = lambda ts: [t.data_ptr() for t in ts]
+    ops.convs_prep_weights(p(w1), p(wf1), None, True, K, K, C1, F1, st)
+    ops.convs_prep_weights(p(w2), p(wf2), None, False, K, K, F1, F2, st)
+    y1 = [torch.full((B * IH * IW * F1 * 2,), -1, dtype=torch.int16, device=dev) for _ in range(G)]
+    ya = [torch.full((B * OH * OW * F2 * 2,), -1, dtype=torch.int16, device=dev) for _ in range(G)]
+    yb = [torch.full_like(t, -2) for t in ya]
+    ma = [torch.full((B * OH * OW * F2 // 8,), 0xAA, dtype=torch.uint8, device=dev) for _ in range(G)]
+    mb = [torch.full_like(t, 0x55) for t in ma]
+    ops.convs_fwd(p(xs), p(wf1), p(b1), p(y1), True, B, IH1, IW1, C1, K, K, S, F1, True, st)
+    ops.convs_fwd(p(y1), p(wf2), p(b2), p(ya), False, B, IH, IW, F1, K, K, S, F2, True, st,
+                  rmasks=[ma[0].data_ptr(), 0, ma[2].data_ptr()])
+    ops.convs_fwd12(p(xs), p(wf1), p(b1), p(wf2), p(b2), p(yb), B, IH1, IW1, C1, F1, F2, True, st,
+                    rmasks=[mb[0].data_ptr(), 0, mb[2].data_ptr()])
+    torch.cuda.synchronize()
+    for g in range(G):
+        assert torch.equal(ya[g], yb[g]), f"fused layer-2 output differs, group {g}"
+    assert torch.equal(ma[0], mb[0]) and torch.equal(ma[2], mb[2]), "ReLU byte mask differs"
+    assert bool((mb[1] == 0x55).all()), "a NULL mask entry must not be written"
+    got = _from_s(ops, yb[0], B * OH * OW, F2, st)
+    assert np.isfinite(got).all() and (got > 0).mean() > 0.05          # not trivially dead
+
+
 # ---------------------------------------------------------------------------------- igemm: dense
 @pytest.mark.parametrize("dims", [(3, 70, 83, 45), (2, 64, 96, 128)])   # ragged (scalar loads) / aligned (float4 loads)
 def test_gemm_variants(dev, prec, dims):
