@@ -19,6 +19,7 @@
 #include <mutex>
 #include <string>
 #include <unordered_map>
+#include <stdlib.h>
 #include <vector>
 
 #include "../../include/serl_hip.h"
@@ -159,6 +160,7 @@ struct serl_learner {
   const float* backbone = nullptr;   // frozen MobileNetV3 parameters (serl_learner_set_backbone)
   // instrumentation
   bool timing = false, phases = false;
+  bool fuse12 = getenv("SERL_AMD_CONV_FUSE12") == nullptr || strcmp(getenv("SERL_AMD_CONV_FUSE12"), "0") != 0;   // A/B switch
   std::vector<TimeRec> trecs;
   std::vector<PhaseRec> precs;
 };
@@ -220,6 +222,12 @@ void conv_cost(int kind, int in_u8, int n, int B, const ConvL& L, double* flops,
   const double y = (double)n * B * L.OH * L.OW * L.F * 4;
   const double w = (double)n * L.K * L.K * L.C * L.F * 4;
   *flops = 2.0 * n * B * L.OH * L.OW * L.F * L.K * L.K * L.C;
+  if (kind == 3) {   // layers 1 + 2 fused (L = layer 1, layer 2 = 3x3 stride 2 -> 64): frames in, layer-2 output out
+    const int oh2 = (L.OH - 3) / 2 + 1, ow2 = (L.OW - 3) / 2 + 1, f2 = 64;
+    *flops += 2.0 * n * B * oh2 * ow2 * f2 * 9.0 * L.F;
+    *bytes = x + w + (double)n * 9 * L.F * f2 * 4 + (double)n * B * oh2 * ow2 * f2 * 4 + n * (L.F + f2) * 4.0;
+    return;
+  }
   if (kind == 0) *bytes = x + w + y + n * L.F * 4.0;
   else if (kind == 1) *bytes = y + w + x / 2 + x;
   else *bytes = x + y + w + n * L.F * 4.0;
@@ -308,32 +316,75 @@ int encoder_fwd(serl_learner* h, const Pass* passes, int npass, int B, Workspace
       }
       DRV(flush());   // every (layer, group) in one launch, ahead of the dependent chain of conv kernels
     }
+    // Passes that nobody differentiates (target critic, actor run-ahead, acting) do not need layer 1's output in
+    // memory: their layers 1 + 2 run as one fused launch (serl_convs_fwd12), the pass whose masks are saved for the
+    // backward (mask_tag) keeps the layer-by-layer launches.
+    bool fused[MAXG_];
+    int nfused = 0;
+    {
+      const bool fits = split && h->fuse12 && nl >= 2 && c.L[0].K == 3 && c.L[0].S == 2 && c.L[1].K == 3 && c.L[1].S == 2 &&
+                        serl_convs_fwd12_supported(c.L[0].IH, c.L[0].IW, c.L[0].C, c.L[0].F, c.L[1].F);
+      for (int i = 0; i < n; ++i) {
+        fused[i] = fits && !(mask_tag && ch[i].p->tag == mask_tag);
+        nfused += fused[i];
+      }
+    }
     for (int li = 0; li < nl; ++li) {
       const ConvL& L = c.L[li];
+      // groups of this layer's plain launch (all of them from layer 2 on)
+      int idx[MAXG_], m = 0;
+      for (int i = 0; i < n; ++i)
+        if (li >= 2 || !fused[i]) idx[m++] = i;
+      const void* xin[MAXG_]; const void* wfp[MAXG_];
       const float* wsp[MAXG_]; const float* bsp[MAXG_]; void* ys[MAXG_]; void* rm[MAXG_];
       bool any_mask = false;
-      for (int i = 0; i < n; ++i) {
+      for (int k = 0; k < m; ++k) {
+        const int i = idx[k];
         const Pass* p = ch[i].p;
-        wsp[i] = p->store.at(p->eo->ck[ch[i].ci][li]);
-        bsp[i] = p->store.at(p->eo->cb[ch[i].ci][li]);
+        xin[k] = xs[i];
+        wfp[k] = split ? wf_all[li][i] : nullptr;
+        wsp[k] = p->store.at(p->eo->ck[ch[i].ci][li]);
+        bsp[k] = p->store.at(p->eo->cb[ch[i].ci][li]);
         WSF(ws, st, y, (size_t)B * L.OH * L.OW * L.F, "act%d_%c_%d", li, p->tag, ch[i].ci);
-        ys[i] = y;
-        rm[i] = nullptr;
+        ys[k] = y;
+        rm[k] = nullptr;
         if (split && mask_tag && li < nl - 1 && p->tag == mask_tag) {
           WSF(ws, st, r, rmask_floats(B, L), "rmask%d_%c_%d", li, p->tag, ch[i].ci);
-          rm[i] = r;
+          rm[k] = r;
           any_mask = true;
         }
       }
-      Timed t{h, st};
-      DRV(t.begin(0, li == 0, n, B, L));
-      if (split)
-        DRV(serl_convs_fwd(n, xs, (const void* const*)wf_all[li], bsp, ys, li == 0, B, L.IH, L.IW, L.C, L.K, L.K, L.S, L.F,
-                           1, any_mask ? rm : nullptr, st));
-      else
-        DRV(serl_conv2d_fwd(n, xs, wsp, bsp, (float* const*)ys, li == 0, B, L.IH, L.IW, L.C, L.K, L.K, L.S, L.F, 1, st));
-      DRV(t.end());
-      for (int i = 0; i < n; ++i) xs[i] = ys[i];
+      if (m > 0) {
+        Timed t{h, st};
+        DRV(t.begin(0, li == 0, m, B, L));
+        if (split)
+          DRV(serl_convs_fwd(m, xin, wfp, bsp, ys, li == 0, B, L.IH, L.IW, L.C, L.K, L.K, L.S, L.F, 1,
+                             any_mask ? rm : nullptr, st));
+        else
+          DRV(serl_conv2d_fwd(m, xin, wsp, bsp, (float* const*)ys, li == 0, B, L.IH, L.IW, L.C, L.K, L.K, L.S, L.F, 1, st));
+        DRV(t.end());
+        for (int k = 0; k < m; ++k) xs[idx[k]] = ys[k];
+      }
+      if (li == 0 && nfused > 0) {
+        const ConvL& L1 = c.L[1];
+        const void* fx[MAXG_]; const void* f1[MAXG_]; const void* f2[MAXG_]; const float* fb1[MAXG_]; const float* fb2[MAXG_];
+        void* fy[MAXG_];
+        int fi[MAXG_], k = 0;
+        for (int i = 0; i < n; ++i) {
+          if (!fused[i]) continue;
+          const Pass* p = ch[i].p;
+          fx[k] = xs[i]; f1[k] = wf_all[0][i]; f2[k] = wf_all[1][i];
+          fb1[k] = p->store.at(p->eo->cb[ch[i].ci][0]); fb2[k] = p->store.at(p->eo->cb[ch[i].ci][1]);
+          WSF(ws, st, y, (size_t)B * L1.OH * L1.OW * L1.F, "act1_%c_%d", p->tag, ch[i].ci);
+          fy[k] = y; fi[k] = i;
+          ++k;
+        }
+        Timed t{h, st};
+        DRV(t.begin(3, 1, k, B, L));
+        DRV(serl_convs_fwd12(k, fx, f1, fb1, f2, fb2, fy, B, L.IH, L.IW, L.C, L.F, L1.F, 1, nullptr, st));
+        DRV(t.end());
+        for (int q = 0; q < k; ++q) xs[fi[q]] = fy[q];
+      }
     }
     const void* feats[MAXG_]; const float* kers[MAXG_]; float* outs[MAXG_];
     for (int i = 0; i < n; ++i) {
