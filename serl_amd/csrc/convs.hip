@@ -724,6 +724,24 @@ static int convs_wgrad_impl(const char* name, int ngroups, const void* const* x,
   int nsplit, klen;
   wgrad_plan(g, ngroups, nsplit, klen);
   const int kkc = KH * KW * C;
+  if (g_patch_kernels && !in_u8 && KH == 3 && KW == 3 && stride == 2 && C == 32 && F == 64 && g.OW <= 31 &&
+      (IW + 1) / 2 <= 32 && workspace != nullptr) {
+    // x band + dz band staged once in LDS, operands read with the transposing LDS load (pconv.h); slabs as below
+    PConvWgradArgs a;
+    a.B = B; a.IH = IH; a.IW = IW; a.OH = g.OH; a.OW = g.OW; a.slab = workspace;
+    a.nbands = cdiv(g.OH, PWgradCfg::R);
+    a.d_bands = make_fastdiv(a.nbands);
+    for (int i = 0; i < ngroups; ++i) { a.x[i] = (const ushort_t*)x[i]; a.dz[i] = (const ushort_t*)dz[i]; }
+    int nslab = 0;
+    if (int e = pconv_wgrad_launch(a, ngroups, workspace_bytes, &nslab, (hipStream_t)stream, name)) return e;
+    if (nslab > 0) {
+      ReduceArgs ra; ra.slab = workspace; ra.nsplit = nslab; ra.kkc = kkc; ra.F = F;
+      for (int i = 0; i < ngroups; ++i) { ra.dw[i] = dw[i]; ra.db[i] = dbias[i]; }
+      launch_wgrad_reduce(ra, ngroups, (hipStream_t)stream);
+      SERL_CHECK_LAUNCH("wgrad_reduce");
+      return SERL_OK;
+    }
+  }
   const long long need = (long long)ngroups * nsplit * (kkc + 1) * F * 4ll;
   SERL_CHECK_ARG(workspace != nullptr && workspace_bytes >= need, "%s: split-K slabs need %lld bytes, %lld available",
                  name, need, workspace_bytes);

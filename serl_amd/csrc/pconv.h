@@ -831,3 +831,199 @@ static int pconv_fused12_launch(const PConvFusedArgs& a, int ngroups, hipStream_
   SERL_CHECK_LAUNCH(name);
   return SERL_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ weight gradient
+// dW[ky][kx][c][f] = sum over (image, oy, ox) x[2 oy + ky][2 ox + kx][c] * dz[oy][ox][f], dbias[f] = sum dz, for the
+// 3x3 stride-2 layer with C = 32, F = 64.  The im2col kernel gathers its A operand (8 channels of one tap of one
+// pixel per 16-byte load, every lane its own cache line) and re-reads dz once per 128-row tile of the 289 rows:
+// 0.28 of the HBM roof.  Here an item is a band of R = 2 output rows of one image: 5 rows of x and 2 rows of dz are
+// staged in LDS by LDS-DMA (double-buffered, layouts of pconv_fwd_kernel / pconv_dgrad_kernel), and both MFMA
+// operands -- k = pixel runs along the records -- are read with ds_read_b64_tr_b16 (hardware transpose).  The
+// 9 taps x 2 halves of F plus an all-ones row for the bias are 20 accumulator tiles = 2 per wave of a 10-wave block;
+// they stay in registers over ALL items of the persistent block, which then writes one fp32 slab; the slabs are summed
+// in a fixed order by wgrad_reduce_kernel (conv_geom.h) as before: reproducible, no atomics.
+// four transposing LDS reads, issued and NOT waited for (the caller's s_waitcnt ties the outputs)
+#define PCONV_TR4(o0, o1, o2, o3, a0, a1, a2, a3)                                                                      \
+  asm volatile("ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %5\n\tds_read_b64_tr_b16 %2, %6\n\tds_read_b64_tr_b16 %3, %7" \
+               : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3)                                                             \
+               : "v"((uint32_t)(a0)), "v"((uint32_t)(a1)), "v"((uint32_t)(a2)), "v"((uint32_t)(a3))                     \
+               : "memory")
+
+struct PConvWgradArgs {
+  const unsigned short* x[MAXG];
+  const unsigned short* dz[MAXG];
+  float* slab;                        // [group][gridDim.x][289 * 64]
+  int B, IH, IW, OH, OW, nbands;
+  FastDiv d_bands;
+};
+
+struct PWgradCfg {
+  static constexpr int C = 32, F = 64, R = 2, NW = 10, NT = 64 * NW;
+  static constexpr int XREC = 4 * C, XPARB = 32 * XREC, XROWB = 2 * XPARB, XROWS = 2 * R + 1;
+  static constexpr int XPATCH = XROWS * XROWB;              // 40 KB
+  static constexpr int ZREC = 4 * F, ZROWB = 32 * ZREC;
+  static constexpr int ZPATCH = R * ZROWB;                  // 16 KB
+  static constexpr int BUF = XPATCH + ZPATCH;
+  static constexpr int LDS = 2 * BUF;
+  static constexpr int XPIECES = XPATCH / 16 / NT;          // 4
+  static constexpr int ZSLOTS = ZPATCH / 16;                // 1024
+  static constexpr int SLAB = (9 * C + 1) * F;              // floats per slab
+  static_assert(XPATCH % (16 * NT) == 0 && LDS <= 160 * 1024, "LDS");
+};
+
+__global__ __launch_bounds__(640, 1) void pconv_wgrad_kernel(const PConvWgradArgs a) {
+  typedef PWgradCfg G;
+  constexpr int C = G::C, F = G::F, R = G::R, NW = G::NW;
+  extern __shared__ __attribute__((aligned(16))) unsigned char p_smem[];
+  const int z = blockIdx.z;
+  const int nitems = a.B * a.nbands;
+  const int per = (nitems + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int it0 = blockIdx.x * per, it1 = min(nitems, it0 + per);    // the launcher sizes the grid so that it0 < it1
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int nt = wid & 1, mt0 = (wid >> 1) * 2;              // N tile; M tiles mt0, mt0 + 1 (tap index, 9 = ones row)
+  const int tr_q = (lane & 15) >> 2, tr_p = lane & 3, tr_cb = lane & 16;
+
+  auto dma = [&](int item, unsigned char* buf) {
+    const int b = (int)fd_div((uint32_t)item, a.d_bands), band = item - b * a.nbands;
+    const int oy0 = band * R;
+    const char* xsrc = reinterpret_cast<const char*>(a.x[z]) + ((size_t)(b * a.IH + 2 * oy0) * a.IW) * G::XREC;
+    const int xrows = min(G::XROWS, a.IH - 2 * oy0);
+#pragma unroll 1
+    for (int i = 0; i < G::XPIECES; ++i) {
+      const int l = (i * NW + wid) * 64 + lane;
+      const int rec = l >> 3, chp = l & 7;
+      const int rr = rec >> 6, par = (rec >> 5) & 1, j = rec & 31;
+      const int ix = 2 * j + par;
+      const bool ok = rr < xrows && ix < a.IW;
+      const char* g = ok ? xsrc + (size_t)(((rr * a.IW + ix) << 3) + (chp ^ pconv_swz<G::XREC>(j))) * 16
+                         : reinterpret_cast<const char*>(g_zero_page);
+      __builtin_amdgcn_global_load_lds((pconv_gptr_t)g, (pconv_lptr_t)(buf + (i * NW + wid) * 1024), 16, 0, 0);
+    }
+    const char* zsrc = reinterpret_cast<const char*>(a.dz[z]) + ((size_t)(b * a.OH + oy0) * a.OW) * G::ZREC;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if ((i * NW + wid) * 64 < G::ZSLOTS) {               // wave-uniform
+        const int l = (i * NW + wid) * 64 + lane;
+        const int rec = l >> 4, chp = l & 15;
+        const int row = rec >> 5, ox = rec & 31;
+        const bool ok = oy0 + row < a.OH && ox < a.OW;
+        const char* g = ok ? zsrc + (size_t)(((row * a.OW + ox) << 4) + (chp ^ (ox & 15))) * 16
+                           : reinterpret_cast<const char*>(g_zero_page);
+        __builtin_amdgcn_global_load_lds((pconv_gptr_t)g, (pconv_lptr_t)(buf + G::XPATCH + (i * NW + wid) * 1024), 16, 0, 0);
+      }
+    }
+  };
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
+  // A fragment of the all-ones row: row 0 = 1.0 for every k
+  const uint32_t one2 = r == 0 ? 0x3F803F80u : 0u;
+  const u32x4_t onesv = {one2, one2, one2, one2};
+  const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, onesv);
+
+  const uint32_t smem_base = (uint32_t)(size_t)(pconv_lptr_t)p_smem;
+  dma(it0, p_smem);
+  int pb = 0;
+  for (int item = it0; item < it1; ++item, pb ^= 1) {
+    const uint32_t xp_base = smem_base + pb * G::BUF, zp_base = xp_base + G::XPATCH;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();            // this item's patches landed; every wave is done with the other buffer
+    if (item + 1 < it1) dma(item + 1, p_smem + (pb ^ 1) * G::BUF);
+#pragma unroll
+    for (int st = 0; st < 2 * R; ++st) {       // k16 step: output row oyl, pixels ox = 16 sx + 0..15
+      const int oyl = st >> 1, sx = st & 1;
+      // this lane feeds the transposed reads with k-rows (pixels) ox0 and ox0 + 4 and 4 consecutive rows (channels).
+      // The reads are hand-written: hipcc puts vmcnt(0) in front of the ds_read_tr builtin while a DMA is in flight.
+      const int ox0 = 16 * sx + 8 * h + tr_q;
+      s16x4_t bq[4], aq[2][4];
+      {
+        const int cofs = (32 * nt + tr_cb + 4 * tr_p) * 2;           // byte offset inside the hi plane of a dz record
+        const int chunk = cofs >> 4, within = cofs & 15;
+        const uint32_t r0 = zp_base + oyl * G::ZROWB + ox0 * G::ZREC + within, r1 = r0 + 4 * G::ZREC;
+        const int s0 = ox0 & 15, s1 = (ox0 + 4) & 15;
+        PCONV_TR4(bq[0], bq[1], bq[2], bq[3], r0 + ((chunk ^ s0) << 4), r1 + ((chunk ^ s1) << 4),
+                  r0 + (((chunk + 8) ^ s0) << 4), r1 + (((chunk + 8) ^ s1) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int mt = mt0 + i;
+        if (mt < 9) {                          // wave-uniform
+          const int ky = mt / 3, kx = mt - 3 * ky;
+          const int cofs = (tr_cb + 4 * tr_p) * 2;                    // byte offset inside the hi plane of an x record
+          const int chunk = cofs >> 4, within = cofs & 15;
+          const int j0 = ox0 + (kx >> 1), j1 = j0 + 4;
+          const uint32_t row = xp_base + ((2 * oyl + ky) * 2 + (kx & 1)) * G::XPARB + within;
+          const uint32_t r0 = row + j0 * G::XREC, r1 = row + j1 * G::XREC;
+          const int s0 = pconv_swz<G::XREC>(j0), s1 = pconv_swz<G::XREC>(j1);
+          PCONV_TR4(aq[i][0], aq[i][1], aq[i][2], aq[i][3], r0 + ((chunk ^ s0) << 4), r1 + ((chunk ^ s1) << 4),
+                    r0 + (((chunk + 4) ^ s0) << 4), r1 + (((chunk + 4) ^ s1) << 4));
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) aq[i][e] = s16x4_t{0, 0, 0, 0};
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]), "+v"(aq[0][0]), "+v"(aq[0][1]), "+v"(aq[0][2]),
+                     "+v"(aq[0][3]), "+v"(aq[1][0]), "+v"(aq[1][1]), "+v"(aq[1][2]), "+v"(aq[1][3]));
+      typedef short s16x8_t __attribute__((ext_vector_type(8)));
+      const bf16x8_t bh = __builtin_bit_cast(bf16x8_t, (s16x8_t){bq[0][0], bq[0][1], bq[0][2], bq[0][3], bq[1][0], bq[1][1], bq[1][2], bq[1][3]});
+      const bf16x8_t bl = __builtin_bit_cast(bf16x8_t, (s16x8_t){bq[2][0], bq[2][1], bq[2][2], bq[2][3], bq[3][0], bq[3][1], bq[3][2], bq[3][3]});
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        if (mt0 + i == 9) {                    // the bias row
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, bl, acc[i], 0, 0, 0);
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, bh, acc[i], 0, 0, 0);
+        } else {
+          const bf16x8_t ah = __builtin_bit_cast(bf16x8_t, (s16x8_t){aq[i][0][0], aq[i][0][1], aq[i][0][2], aq[i][0][3], aq[i][1][0], aq[i][1][1], aq[i][1][2], aq[i][1][3]});
+          const bf16x8_t al = __builtin_bit_cast(bf16x8_t, (s16x8_t){aq[i][2][0], aq[i][2][1], aq[i][2][2], aq[i][2][3], aq[i][3][0], aq[i][3][1], aq[i][3][2], aq[i][3][3]});
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[i], 0, 0, 0);
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i], 0, 0, 0);
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // ---- one slab per block: rows (tap, c) in HWIO order, then the bias row
+  float* slab = a.slab + ((size_t)z * gridDim.x + blockIdx.x) * G::SLAB;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int mt = mt0 + i;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int m = (q & 3) + 8 * (q >> 2) + 4 * h;
+      if (mt < 9) slab[(size_t)(mt * C + m) * F + nt * 32 + r] = acc[i][q];
+      else if (m == 0) slab[(size_t)(9 * C) * F + nt * 32 + r] = acc[i][q];
+    }
+  }
+}
+
+// returns the number of slabs per group through *nslab (0: the workspace cannot hold even one block's slabs)
+static int pconv_wgrad_launch(PConvWgradArgs& a, int ngroups, long long workspace_bytes, int* nslab, hipStream_t st,
+                              const char* name) {
+  static bool opted[64] = {};
+  static int ncu[64] = {};
+  int dev = 0;
+  SERL_CHECK_HIP(hipGetDevice(&dev), name);
+  SERL_CHECK_ARG(dev >= 0 && dev < 64, "%s: device ordinal %d out of range", name, dev);
+  if (!opted[dev]) {
+    SERL_CHECK_HIP(hipFuncSetAttribute((const void*)pconv_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PWgradCfg::LDS), name);
+    SERL_CHECK_HIP(hipDeviceGetAttribute(&ncu[dev], hipDeviceAttributeMultiprocessorCount, dev), name);
+    opted[dev] = true;
+  }
+  const int nitems = a.B * a.nbands;
+  int gx = (ncu[dev] > 0 ? ncu[dev] : 256) / ngroups;
+  const long long fit = workspace_bytes / ((long long)ngroups * PWgradCfg::SLAB * 4);
+  if (gx > fit) gx = (int)fit;
+  if (gx > nitems) gx = nitems;
+  if (gx < 1) { *nslab = 0; return SERL_OK; }
+  const int per = cdiv(nitems, gx);
+  gx = cdiv(nitems, per);                    // every block has at least one item
+  *nslab = gx;
+  hipLaunchKernelGGL(pconv_wgrad_kernel, dim3(gx, 1, ngroups), dim3(PWgradCfg::NT), PWgradCfg::LDS, st, a);
+  SERL_CHECK_LAUNCH(name);
+  return SERL_OK;
+}
