@@ -591,7 +591,7 @@ struct PFusedCfg {
   static constexpr int U8BUF = 3 * NT * 16;              // 24 KB >= U8ROWS * RB1MAX + slack, 3 DMA pieces per thread
   static constexpr int W1IMG = 6 * 2 * 32 * 32;          // layer-1 weights as B fragments: [k16 step][plane][f][2 x 16 B]
   static constexpr int LDS = G2::PATCH + 2 * U8BUF + W1IMG;
-  static_assert(U8ROWS * RB1MAX + 64 <= U8BUF && LDS <= 160 * 1024, "LDS");
+  static_assert(U8ROWS * RB1MAX + 64 <= U8BUF && LDS <= 160 * 1024 && G2::ROWB == 16 * NT, "LDS");
 };
 
 __global__ __launch_bounds__(512, 1) void pconv_fused12_kernel(const PConvFusedArgs a) {
@@ -698,10 +698,26 @@ __global__ __launch_bounds__(512, 1) void pconv_fused12_kernel(const PConvFusedA
     else if (mk != nullptr) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    // The last layer-1 row of a band is the first row of the next band of the same image: when this block computed it
+    // for the previous item it is copied (8 KB, LDS to LDS) instead of recomputed -- 16 tiles = two full rounds of the
+    // 8 waves instead of 18 = three.  (The output tile of the previous item overlays rows 0..4 only.)
+    const bool reuse = item > it0 && band > 0;
+    if (reuse && wid >= 6) {
+      // copied by the very waves that overwrite that half of the last row in their second round (tiles 16, 17 belong
+      // to waves 6, 7): program order inside a wave puts the read before the write, no barrier needed
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int off = (k >> 1) * PARB + (wid - 6) * 16 * REC + (k & 1) * 1024 + lane * 16;
+        *reinterpret_cast<u32x4_t*>(patch + off) = *reinterpret_cast<const u32x4_t*>(patch + 2 * R * ROWB + off);
+      }
+    }
     if (item + 1 < it1) dma_u8(item + 1, u8buf + (pb ^ 1) * U8BUF);
 
     // ---- layer 1: 2 x nrows1 tiles of 32 pixels (row y1, columns 32 half .. + 31), round-robin over the 8 waves
-    for (int t = wid; t < 2 * nrows1; t += 8) {
+#ifdef PF_NO_C1      // ablation builds
+    if (item == it0)
+#endif
+    for (int t = (reuse ? 2 : 0) + wid; t < 2 * nrows1; t += 8) {
       const int y1 = t >> 1, ox1 = (t & 1) * 32 + r;
       f32x16 acc1;
 #pragma unroll
@@ -712,9 +728,8 @@ __global__ __launch_bounds__(512, 1) void pconv_fused12_kernel(const PConvFusedA
         const uint32_t ad = (uint32_t)((2 * y1 + (s >> 1)) * RB1 + 2 * ox1 * a.C1 + (s & 1) * 16 + 8 * h);
         const uint32_t* p = reinterpret_cast<const uint32_t*>(ub + (ad & ~3u));
         const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
-        const bool odd = (ad & 2u) != 0;
-        const uint32_t lo4 = odd ? __builtin_amdgcn_alignbyte(d1, d0, 2) : d0;
-        const uint32_t hi4 = odd ? __builtin_amdgcn_alignbyte(d2, d1, 2) : d1;
+        const uint32_t lo4 = __builtin_amdgcn_alignbyte(d1, d0, ad & 2u);
+        const uint32_t hi4 = __builtin_amdgcn_alignbyte(d2, d1, ad & 2u);
         const uint2 e0 = u8x4_to_bf16(lo4), e1 = u8x4_to_bf16(hi4);
         const u32x4_t av = {e0.x, e0.y, e1.x, e1.y};
         const bf16x8_t ah = __builtin_bit_cast(bf16x8_t, av);
@@ -749,6 +764,9 @@ __global__ __launch_bounds__(512, 1) void pconv_fused12_kernel(const PConvFusedA
     f32x16 acc;
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#ifdef PF_NO_C2
+    if (item == it0)
+#endif
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int ky = tap / 3, kx = tap - 3 * ky;
