@@ -160,6 +160,7 @@ struct serl_learner {
   const float* backbone = nullptr;   // frozen MobileNetV3 parameters (serl_learner_set_backbone)
   // instrumentation
   bool timing = false, phases = false;
+  int wg_main_layers = getenv("SERL_AMD_WG_MAIN_LAYERS") ? atoi(getenv("SERL_AMD_WG_MAIN_LAYERS")) : 1;   // A/B switch
   bool fuse12 = getenv("SERL_AMD_CONV_FUSE12") == nullptr || strcmp(getenv("SERL_AMD_CONV_FUSE12"), "0") != 0;   // A/B switch
   std::vector<TimeRec> trecs;
   std::vector<PhaseRec> precs;
@@ -449,15 +450,23 @@ int encoder_bwd(serl_learner* h, char tag, const Store& store, const EncOff& eo,
       dw[ci] = grads.at(eo.ck[ci][li]);
       db[ci] = grads.at(eo.cb[ci][li]);
     }
+    // The side stream carries more work than the main stream's data-gradient chain: the first layer's weight gradient,
+    // which becomes ready last, runs on the main stream behind the last data gradient (its own slabs).
+    const bool on_main = gside && li < h->wg_main_layers && nl > 1;
     hipStream_t sw = st;
-    if (gside) DRV(gside->fork(&sw));   // dz of this layer is ready on the main stream here
+    if (gside && !on_main) DRV(gside->fork(&sw));   // dz of this layer is ready on the main stream here
+    float* slab_l = slab;
+    if (on_main) {
+      WSF(ws, st, slab1, (size_t)slab_bytes / 4, "wgrad_slab_main");
+      slab_l = slab1;
+    }
     {
       Timed t{h, sw};
       DRV(t.begin(2, li == 0, ncam, B, L));
       if (split)
-        DRV(serl_convs_wgrad(ncam, xs, dz, dw, db, slab, slab_bytes, li == 0, B, L.IH, L.IW, L.C, L.K, L.K, L.S, L.F, sw));
+        DRV(serl_convs_wgrad(ncam, xs, dz, dw, db, slab_l, slab_bytes, li == 0, B, L.IH, L.IW, L.C, L.K, L.K, L.S, L.F, sw));
       else
-        DRV(serl_conv2d_wgrad(ncam, xs, (const float* const*)dz, dw, db, slab, slab_bytes, li == 0, B, L.IH, L.IW, L.C,
+        DRV(serl_conv2d_wgrad(ncam, xs, (const float* const*)dz, dw, db, slab_l, slab_bytes, li == 0, B, L.IH, L.IW, L.C,
                               L.K, L.K, L.S, L.F, sw));
       DRV(t.end());
     }
