@@ -61,6 +61,14 @@ struct PFwdCfg {
   static_assert(EPI <= PATCH && WIMG <= LDS && LDS <= 160 * 1024, "LDS");
 };
 
+// CUs a persistent grid spreads over (all of them; SERL_PCONV_CUS caps it for experiments with co-running streams)
+static int pconv_cus(int ncu) {
+  static int cap = -1;
+  if (cap < 0) { const char* e = getenv("SERL_PCONV_CUS"); cap = e ? atoi(e) : 0; }
+  const int n = ncu > 0 ? ncu : 256;
+  return cap > 0 && cap < n ? cap : n;
+}
+
 typedef __attribute__((address_space(1))) const void* pconv_gptr_t;
 typedef __attribute__((address_space(3))) void* pconv_lptr_t;
 
@@ -289,7 +297,7 @@ static int pconv_fwd_launch(const PConvFwdArgs& a, int ngroups, hipStream_t st, 
     const char* e = getenv("SERL_PCONV_ITEMS");
     items_per_block = e ? atoi(e) : 0;
   }
-  int gx = (ncu[dev] > 0 ? ncu[dev] : 256) / ngroups;
+  int gx = pconv_cus(ncu[dev]) / ngroups;
   if (items_per_block > 0) gx = cdiv(nitems, items_per_block);
   if (gx < 1) gx = 1;
   if (gx > nitems) gx = nitems;
@@ -553,7 +561,7 @@ static int pconv_dgrad_launch(const PConvDgradArgs& a, int ngroups, hipStream_t 
     opted[dev] = true;
   }
   const int nitems = a.B * a.nbands;
-  int gx = (ncu[dev] > 0 ? ncu[dev] : 256) / ngroups;
+  int gx = pconv_cus(ncu[dev]) / ngroups;
   if (gx < 1) gx = 1;
   if (gx > nitems) gx = nitems;
   hipLaunchKernelGGL(pconv_dgrad_kernel, dim3(gx, 1, ngroups), dim3(PDgradCfg::NT), PDgradCfg::LDS, st, a);
@@ -842,7 +850,7 @@ static int pconv_fused12_launch(const PConvFusedArgs& a, int ngroups, hipStream_
     opted[dev] = true;
   }
   const int nitems = a.B * a.nbands;
-  int gx = (ncu[dev] > 0 ? ncu[dev] : 256) / ngroups;
+  int gx = pconv_cus(ncu[dev]) / ngroups;
   if (gx < 1) gx = 1;
   if (gx > nitems) gx = nitems;
   hipLaunchKernelGGL(pconv_fused12_kernel, dim3(gx, 1, ngroups), dim3(PFusedCfg::NT), PFusedCfg::LDS, st, a);
@@ -1033,7 +1041,7 @@ static int pconv_wgrad_launch(PConvWgradArgs& a, int ngroups, long long workspac
     opted[dev] = true;
   }
   const int nitems = a.B * a.nbands;
-  int gx = (ncu[dev] > 0 ? ncu[dev] : 256) / ngroups;
+  int gx = pconv_cus(ncu[dev]) / ngroups;
   const long long fit = workspace_bytes / ((long long)ngroups * PWgradCfg::SLAB * 4);
   if (gx > fit) gx = (int)fit;
   if (gx > nitems) gx = nitems;
