@@ -9,6 +9,7 @@
 #include "conv_geom.h"
 #include "sgemm.h"
 #include "pconv.h"
+#include "sgemm_ring.h"
 
 typedef unsigned short ushort_t;
 
@@ -577,11 +578,24 @@ extern "C" int serl_convs_prep_weights_multi(int njobs, const float* const* w, v
 
 // The patch kernels (pconv.h) are chosen wherever the layer fits them; 0 keeps every layer on the im2col kernels (A/B
 // measurements and the bit-identity test of the two paths).  Process-wide.
-static int g_patch_kernels = 1;
+// enable: 0 = im2col kernels only, 1 (default) = patch kernels incl. the wide one (pconv_fwdw_kernel), 2 = the 8-wave
+// patch kernels only, 3 = as 1 plus the LDS-DMA ring GEMM (sgemm_ring.h, also bit-identical) for the deep layers no patch
+// kernel takes.  The ring GEMM is 5-8 % faster than the register-staged kernel stand-alone but takes the CU's whole LDS
+// (one block per CU), so nothing of the other streams runs next to it: -1 % on the whole update, hence not the default.
+static int g_patch_kernels = 1, g_ring_kernels = 0, g_wide_kernels = 1;
 extern "C" int serl_convs_set_patch_kernels(int enable) {
   g_patch_kernels = enable ? 1 : 0;
+  g_ring_kernels = enable == 3 ? 1 : 0;
+  g_wide_kernels = enable == 1 || enable == 3 ? 1 : 0;
   return SERL_OK;
 }
+
+#ifndef S_RING_FWD
+#define S_RING_FWD RingCfg<256, 128, 4, 2, 3>     // 8 waves, 64 x 64 per wave, three K slabs of 32 in flight
+#endif
+#ifndef S_RING_FWD256
+#define S_RING_FWD256 RingCfg<128, 256, 2, 4, 3>  // N = 256 in one tile: the im2col operand is fetched once, not per column tile
+#endif
 
 extern "C" int serl_convs_fwd(int ngroups, const void* const* x, const void* const* wf, const float* const* bias,
                               void* const* y, int in_u8, int B, int IH, int IW, int C, int KH, int KW, int stride, int F,
@@ -597,10 +611,20 @@ extern "C" int serl_convs_fwd(int ngroups, const void* const* x, const void* con
   if (g_patch_kernels && !in_u8 && KH == 3 && KW == 3 && stride == 2) {
     // 3x3 stride-2 layers whose row fits the patch layout: input rows staged once in LDS (pconv.h), bit-identical output
     const bool fit32 = C == 32 && F == 64 && g.OW <= 32 && (IW + 1) / 2 <= 32;
-    // (C = 64 -> 128 at OW <= 16 fits too, a C = 64 patch with a streamed weight slab, but measured 2x slower than im2col: 48 pixels
-    //  per block against 295 KB of weights; that layer is not over-fetch bound)
-    const bool fit16 = false;
-    if (fit32 || fit16) {
+    // C = 64 -> 128 at OW <= 16: four waves with the whole weight matrix in their registers (pconv_fwdw_kernel)
+    const bool fit16 = g_wide_kernels && C == 64 && F == 128 && g.OW <= 16 && (IW + 1) / 2 <= 16;
+    if (fit16) {
+      PConvFwdArgs a;
+      a.B = B; a.IH = IH; a.IW = IW; a.OH = g.OH; a.OW = g.OW; a.relu = relu;
+      a.nbands = cdiv(g.OH, 4);
+      a.d_iw = make_fastdiv(IW); a.d_bands = make_fastdiv(a.nbands);
+      for (int i = 0; i < ngroups; ++i) {
+        a.x[i] = (const ushort_t*)x[i]; a.wf[i] = (const ushort_t*)wf[i]; a.bias[i] = bias[i]; a.y[i] = (ushort_t*)y[i];
+        a.rmask[i] = rmask ? (unsigned char*)rmask[i] : nullptr;
+      }
+      return pconv_fwdw_launch<PFwdWCfg<64, 128, 4, 16>>(a, ngroups, st, "convs_fwd(patch, wide)");
+    }
+    if (fit32) {
       PConvFwdArgs a;
       a.B = B; a.IH = IH; a.IW = IW; a.OH = g.OH; a.OW = g.OW; a.relu = relu;
       a.nbands = cdiv(g.OH, fit32 ? 4 : 3);
@@ -620,7 +644,10 @@ extern "C" int serl_convs_fwd(int ngroups, const void* const* x, const void* con
     p.rmask[i] = rmask ? (unsigned char*)rmask[i] : nullptr;                                                 \
   }
   if (in_u8) { ConvFwdS<true> p; FILL(p) return s_launch_by_n(S_FWD, p, M, F, 1, ngroups, st, "convs_fwd_u8"); }
-  ConvFwdS<false> p; FILL(p) return s_launch_by_n(S_FWD, p, M, F, 1, ngroups, st, "convs_fwd");
+  ConvFwdS<false> p; FILL(p)
+  if (g_ring_kernels && F > 128 && p.Kp >= 256) return sgemm_ring_launch<ConvFwdS<false>, S_RING_FWD256>(p, M, F, ngroups, st, "convs_fwd(ring)");
+  if (g_ring_kernels && F == 128 && p.Kp >= 256) return sgemm_ring_launch<ConvFwdS<false>, S_RING_FWD>(p, M, F, ngroups, st, "convs_fwd(ring)");
+  return s_launch_by_n(S_FWD, p, M, F, 1, ngroups, st, "convs_fwd");
 #undef FILL
 }
 

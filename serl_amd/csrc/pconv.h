@@ -306,6 +306,248 @@ static int pconv_fwd_launch(const PConvFwdArgs& a, int ngroups, hipStream_t st, 
   return SERL_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ forward, wide layers
+// The same patch forward for a layer whose weight matrix no longer fits the registers of an 8-wave block (C = 64 ->
+// F = 128: 9C x F x 2 planes = 295 KB): FOUR waves, one per SIMD, so that each may use the whole 512-register budget of
+// its SIMD (hipcc spreads them over VGPRs and AGPRs; the MFMA B operand is read from either).  Wave w keeps the B
+// fragments of output channels [32 w, 32 w + 32) for the whole K range (9C/16 x 8 = 288 registers) and multiplies ALL
+// M tiles of the item by them (MT independent accumulators, which also keeps the MFMA pipe of its SIMD full without a
+// second wave).  The im2col GEMM this replaces fetches every input line 2.25 times and streams the weights once per
+// row tile; with the 4 MB L2 thrashed by the 32 blocks of an XCD both come from the Infinity Cache at ~6 TB/s (ablation:
+// 155 us with real operands, 93 us when every load hits).  Here the input is read once (+ one halo row per band) and the
+// weights once per persistent block.  Same k order and MFMA sequence per accumulator: bit-identical output.
+template <int C_, int F_, int R_, int OWP_>
+struct PFwdWCfg {
+  static constexpr int C = C_, F = F_, R = R_, OWP = OWP_;
+  static constexpr int NW = F_ / 32, NT = 64 * NW;
+  static constexpr int REC = 4 * C, NCH = C / 4;
+  static constexpr int NR = 2 * R + 1;
+  static constexpr int ROWB = 2 * OWP * REC;
+  static constexpr int PATCH = NR * ROWB;
+  static constexpr int SLOTS = PATCH / 16, NDMA = SLOTS / NT;
+  static constexpr int MT = (R * OWP + 31) / 32;
+  static constexpr int KP = 9 * C, NS = KP / 16;
+  static constexpr int EPI = MT * 32 * (F + 4) * 4;
+  static constexpr int LDS = 2 * PATCH;
+  static constexpr int CH = F / 8, RPP = NT / CH, PASSES = MT * 32 / RPP;
+  static_assert(NW == 4, "one wave per SIMD");
+  static_assert(C % 16 == 0 && 32 % OWP == 0 && (R * OWP) % 32 == 0 && SLOTS % NT == 0 && NDMA * 2 == NS, "shape");
+  static_assert(EPI <= PATCH && LDS <= 160 * 1024, "LDS");
+  static_assert(PASSES * 3 <= 63, "store count of the counted wait");
+};
+
+template <class G>
+__global__ __launch_bounds__(G::NT, 1) void pconv_fwdw_kernel(const PConvFwdArgs a) {
+  constexpr int C = G::C, F = G::F, R = G::R, OWP = G::OWP, NT = G::NT, NW = G::NW, MT = G::MT;
+  constexpr int REC = G::REC, NCH = G::NCH, ROWB = G::ROWB, PARB = OWP * REC;
+  constexpr int RPT = 32 / OWP;
+  constexpr int KS = C / 16, NS = G::NS, Kp = G::KP;
+  extern __shared__ __attribute__((aligned(16))) unsigned char p_smem[];
+
+  const int z = blockIdx.z;
+  const int nitems = a.B * a.nbands;
+  const int per = (nitems + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int it0 = blockIdx.x * per, it1 = min(nitems, it0 + per);
+  if (it0 >= it1) return;                                   // block-uniform, before any barrier
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+
+  constexpr int NDMA = G::NDMA;
+  struct DmaSrc { const char* src; int nrows; };
+  auto dma_src = [&](int item) {
+    const int b = (int)fd_div((uint32_t)item, a.d_bands), band = item - b * a.nbands;
+    const int oy0 = band * R;
+    DmaSrc d;
+    d.nrows = 2 * min(R, a.OH - oy0) + 1;
+    d.src = reinterpret_cast<const char*>(a.x[z]) + ((size_t)(b * a.IH + 2 * oy0) * a.IW) * REC;
+    return d;
+  };
+  auto dma_piece = [&](const DmaSrc& d, unsigned char* patch, int i, bool on) {      // piece i of NDMA: NW waves x 64 slots
+    const int l = (i * NW + wid) * 64 + lane;
+    const int rec = l / NCH, chp = l & (NCH - 1);
+    const int rr = rec / (2 * OWP), par = (rec / OWP) & 1, j = rec & (OWP - 1);
+    const int ix = 2 * j + par;
+#ifdef PCONVW_ZERO_SRC   // ablation build: every patch DMA reads the zero page
+    const bool ok = false;
+#else
+    const bool ok = on && rr < d.nrows && ix < a.IW;
+#endif
+    const char* g = ok ? d.src + (size_t)(((rr * a.IW + ix) * NCH + (chp ^ pconv_swz<REC>(j))) * 16)
+                       : reinterpret_cast<const char*>(g_zero_page);
+    __builtin_amdgcn_global_load_lds((pconv_gptr_t)g, (pconv_lptr_t)(patch + (i * NW + wid) * 1024), 16, 0, 0);
+  };
+  {   // the first patch is on its way while the weights are loaded
+    const DmaSrc d0 = dma_src(it0);
+#pragma unroll 1
+    for (int i = 0; i < NDMA; ++i) dma_piece(d0, p_smem, i, true);
+  }
+
+  // ---- weights: lane (r, h) holds k = 16 s + 8 h .. + 7 of output channel f = 32 wid + r for every k16 step s, straight
+  // from the [F][2][Kp] layout (each lane walks its own row: once per persistent block)
+  bf16x8_t rbh[NS], rbl[NS];
+  {
+#ifdef PCONVW_ZERO_W    // ablation build: weights from the zero page (64 lanes, 128 bytes)
+    const unsigned short* wrow = reinterpret_cast<const unsigned short*>(g_zero_page) + h * 8 - (wid < 0 ? Kp : 0);
+#else
+    const unsigned short* wrow = a.wf[z] + (size_t)((wid * 32 + r) * 2) * Kp + h * 8;
+#endif
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      rbh[s] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(wrow + s * 16));
+      rbl[s] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(wrow + Kp + s * 16));
+    }
+  }
+
+  // ---- fragment addresses of this lane (the same for every item)
+  const int ox = r & (OWP - 1);
+  int arow[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) arow[m] = 2 * min(m * RPT + r / OWP, R - 1) * ROWB;
+  const int rec0 = ox * REC, rec1 = (ox + 1) * REC;
+  const int sw0 = pconv_swz<REC>(ox) << 4, sw1 = pconv_swz<REC>(ox + 1) << 4;
+  constexpr int LDC = F + 4;
+  constexpr int CH = G::CH, RPP = G::RPP;
+  const int n = (tid % CH) * 8;
+  float bs[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) bs[j] = a.bias[z][n + j];
+  unsigned short* const out = a.y[z];
+  unsigned char* const mk = a.rmask[z];
+  // every ordinary load of the block is done before the item loop: inside it only the DMA and the stores are counted
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  int pb = 0;
+  for (int item = it0; item < it1; ++item, pb ^= 1) {
+    unsigned char* const patch = p_smem + pb * G::PATCH;
+    const int b = (int)fd_div((uint32_t)item, a.d_bands), band = item - b * a.nbands;
+    const int oy0 = band * R;
+    const int rows_here = min(R, a.OH - oy0);
+    // this item's patch has landed; the stores of the previous item are younger than its DMA and vmcnt retires in
+    // order, so the wait leaves exactly those stores in flight (2, or 3 with a byte mask, per pass)
+    if (item == it0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else if (mk != nullptr) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(3 * G::PASSES) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * G::PASSES) : "memory");
+    __builtin_amdgcn_s_barrier();
+    const bool more = item + 1 < it1;
+    const DmaSrc dn = dma_src(more ? item + 1 : item);
+    unsigned char* const npatch = p_smem + (pb ^ 1) * G::PATCH;
+
+    f32x16 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[m][q] = 0.f;
+    // One wave per SIMD: nobody else hides this wave's LDS latency, so the A fragments of k16 step s + 1 are requested
+    // before the MFMAs of step s (pinned with sched_barrier), and the accumulators of the M tiles alternate so that no
+    // MFMA waits for the one issued just before it.
+    bf16x8_t fh[2][MT], fl[2][MT];
+    auto frags = [&](int s, int buf) {
+      const int tap = s / KS, kc = s - tap * KS;
+      const int ky = tap / 3, kx = tap - 3 * ky;
+      const int tapoff = ky * ROWB + (kx & 1) * PARB + (kx == 2 ? rec1 : rec0);
+      const int sw = kx == 2 ? sw1 : sw0;
+      const int chh = ((kc * 2 + h) << 4) ^ sw, chl = ((kc * 2 + h + C / 8) << 4) ^ sw;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        fh[buf][m] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(patch + arow[m] + tapoff + chh));
+        fl[buf][m] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(patch + arow[m] + tapoff + chl));
+      }
+    };
+    frags(0, 0);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int cb = s & 1;
+      if (s + 1 < NS) frags(s + 1, cb ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl[cb][m], rbh[s], acc[m], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[cb][m], rbl[s], acc[m], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[cb][m], rbh[s], acc[m], 0, 0, 0);
+      // the next item's DMA pieces behind the first NDMA / 2 k16 steps (early: the patch has the rest of the item to land); branch-free (behind the last item the pieces
+      // copy zeros into the idle buffer): a branch here makes hipcc wait lgkmcnt(0) at the join, prefetch included
+      if (2 * s < NDMA) {
+        dma_piece(dn, npatch, 2 * s, more);
+        dma_piece(dn, npatch, 2 * s + 1, more);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    pconv_lds_barrier();                   // every wave is done with the patch before the output tile overwrites it
+
+    // ---- S-format output through an fp32 tile in LDS (as sgemm.h): 8 consecutive channels of one pixel per thread
+    float* const Cs = reinterpret_cast<float*>(patch);
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = m * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+        Cs[row * LDC + wid * 32 + r] = acc[m][q];
+      }
+    pconv_lds_barrier();
+    // every thread runs every pass and issues the same number of stores (rows past the band's end and the padding
+    // column are redirected to the last valid row / column), so that the wait at the top of the next item is a COUNT
+    const uint32_t cs_base = (uint32_t)(size_t)(pconv_lptr_t)Cs;
+#pragma unroll
+    for (int pass = 0; pass < G::PASSES; ++pass) {
+      const int row0 = tid / CH + pass * RPP;
+      const int oyl = min(row0 / OWP, rows_here - 1), oxx = min(row0 & (OWP - 1), a.OW - 1);
+      const int row = oyl * OWP + oxx;
+      const size_t pix = (size_t)(b * a.OH + oy0 + oyl) * a.OW + oxx;
+      u32x4_t c0, c1;      // LDS reads by hand (pconv_fwd_kernel): no compiler-inserted vmcnt(0) behind the DMA
+      asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&v"(c0), "=&v"(c1) : "v"(cs_base + (uint32_t)(row * LDC + n) * 4u) : "memory");
+      float v[8] = {__uint_as_float(c0[0]), __uint_as_float(c0[1]), __uint_as_float(c0[2]), __uint_as_float(c0[3]),
+                    __uint_as_float(c1[0]), __uint_as_float(c1[1]), __uint_as_float(c1[2]), __uint_as_float(c1[3])};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        v[j] = fmaf(v[j], 1.0f, bs[j]);
+        if (a.relu) v[j] = fmaxf(v[j], 0.f);
+      }
+      u32x4_t hi, lo;
+      uint32_t hh, ll;
+      split_pair(v[0], v[1], hh, ll); hi[0] = hh; lo[0] = ll;
+      split_pair(v[2], v[3], hh, ll); hi[1] = hh; lo[1] = ll;
+      split_pair(v[4], v[5], hh, ll); hi[2] = hh; lo[2] = ll;
+      split_pair(v[6], v[7], hh, ll); hi[3] = hh; lo[3] = ll;
+      unsigned short* dst = out + pix * 2 * F + n;
+      *reinterpret_cast<u32x4_t*>(dst) = hi;
+      *reinterpret_cast<u32x4_t*>(dst + F) = lo;
+      if (mk != nullptr) {
+        uint32_t bits = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          bits |= (hi[j] & 0x7fffu) ? (1u << (2 * j)) : 0u;
+          bits |= (hi[j] & 0x7fff0000u) ? (2u << (2 * j)) : 0u;
+        }
+        mk[pix * (F >> 3) + (n >> 3)] = (unsigned char)bits;
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no DMA may still be landing when the block's LDS is handed on
+}
+
+template <class G>
+static int pconv_fwdw_launch(const PConvFwdArgs& a, int ngroups, hipStream_t st, const char* name) {
+  static bool opted[64] = {};
+  static int ncu[64] = {};
+  int dev = 0;
+  SERL_CHECK_HIP(hipGetDevice(&dev), name);
+  SERL_CHECK_ARG(dev >= 0 && dev < 64, "%s: device ordinal %d out of range", name, dev);
+  if (!opted[dev]) {
+    SERL_CHECK_HIP(hipFuncSetAttribute((const void*)pconv_fwdw_kernel<G>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS), name);
+    SERL_CHECK_HIP(hipDeviceGetAttribute(&ncu[dev], hipDeviceAttributeMultiprocessorCount, dev), name);
+    opted[dev] = true;
+  }
+  const int nitems = a.B * a.nbands;
+  int gx = pconv_cus(ncu[dev]) / ngroups;
+  if (gx < 1) gx = 1;
+  if (gx > nitems) gx = nitems;
+  hipLaunchKernelGGL((pconv_fwdw_kernel<G>), dim3(gx, 1, ngroups), dim3(G::NT), G::LDS, st, a);
+  SERL_CHECK_LAUNCH(name);
+  return SERL_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ data gradient
 // dx = conv_transpose(dz, w) for a 3x3 stride-2 layer with C = 32, F = 64, masked by the ReLU byte mask of x.
 // Per parity class (py, px) of input pixels the taps with ky = py (mod 2), kx = px (mod 2) contribute:

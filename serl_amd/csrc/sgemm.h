@@ -61,6 +61,70 @@ constexpr int sgemm_lds_bytes() {
   return stage > epi ? stage : epi;
 }
 
+// ---- S-format output through LDS (shared by sgemm_kernel and sgemm_ring_kernel): the accumulators (column on the
+// lane, rows in registers) are laid out as an fp32 tile in `smem` (BM x (BN + 4) floats; the caller has made sure that
+// nobody reads the staging images any more), then every thread finishes 8 consecutive channels of one row: bias / ReLU /
+// mask, split into hi and lo, two 16-byte stores -- 8x fewer (and full-width) store instructions than one 2-byte store
+// per element.
+template <class P, int BM, int BN, int NT, int TM, int TN>
+__device__ __forceinline__ void sgemm_s_epilogue(const P& p, const typename P::Ctx& ctx, f32x16 (&acc)[TM][TN],
+                                                 unsigned char* smem, int M, int N, int m0, int n0, int wm, int wn,
+                                                 int r, int h, int tid) {
+  constexpr int LDC = BN + 4;
+  float* Cs = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = wm * (TM * 32) + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+        Cs[row * LDC + wn * (TN * 32) + j * 32 + r] = acc[i][j][q];
+      }
+  __syncthreads();
+  constexpr int CH = BN / 8, RPP = NT / CH;          // chunks per row, rows per pass
+  const int ch = tid % CH, rr = tid / CH;
+  const int n = n0 + ch * 8;
+  if (n < N) {
+    typename P::SCol sc;
+    p.s_col(ctx, n, sc);
+    unsigned short* out = p.s_out(ctx);
+#pragma unroll 2
+    for (int row = rr; row < BM; row += RPP) {
+      const int m = m0 + row;
+      if (m >= M) break;
+      typename P::ORow orow;
+      p.o_row(ctx, m, orow);
+      const float4 v0 = *reinterpret_cast<const float4*>(Cs + row * LDC + ch * 8);
+      const float4 v1 = *reinterpret_cast<const float4*>(Cs + row * LDC + ch * 8 + 4);
+      float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+      p.s_finish(ctx, orow, sc, n, v);
+      u32x4_t hi, lo;
+      uint32_t hh, ll;
+      split_pair(v[0], v[1], hh, ll); hi[0] = hh; lo[0] = ll;
+      split_pair(v[2], v[3], hh, ll); hi[1] = hh; lo[1] = ll;
+      split_pair(v[4], v[5], hh, ll); hi[2] = hh; lo[2] = ll;
+      split_pair(v[6], v[7], hh, ll); hi[3] = hh; lo[3] = ll;
+      unsigned short* dst = out + p.s_base(orow) + n;
+      *reinterpret_cast<u32x4_t*>(dst) = hi;
+      *reinterpret_cast<u32x4_t*>(dst + N) = lo;
+      if constexpr (P::MASK_OUT) {
+        // 1 bit per element "hi plane != 0" (the ReLU mask the data gradient of the next layer needs): a byte per
+        // 8 channels instead of a 16-byte read of the hi plane (a full 128-byte line per pixel when C = 32)
+        if (unsigned char* mk = p.s_mask(ctx)) {
+          uint32_t bits = 0;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            bits |= (hi[j] & 0x7fffu) ? (1u << (2 * j)) : 0u;
+            bits |= (hi[j] & 0x7fff0000u) ? (2u << (2 * j)) : 0u;
+          }
+          mk[(size_t)p.s_pix(orow) * (N >> 3) + (n >> 3)] = (unsigned char)bits;
+        }
+      }
+    }
+  }
+}
+
 #ifndef SG_MIN_WAVES
 #define SG_MIN_WAVES 2
 #endif
@@ -326,64 +390,9 @@ __global__ __launch_bounds__(T::NT, SG_MIN_WAVES) void sgemm_kernel(const P p) {
 #endif
   }
   if constexpr (P::S_OUT) {
-    // ---- S-format output through LDS: the accumulators (column on the lane, rows in registers) are laid out as an
-    // fp32 tile, then every thread finishes 8 consecutive channels of one row: bias / ReLU / mask, split into hi
-    // and lo, two 16-byte stores -- 8x fewer (and full-width) store instructions than one 2-byte store per element.
-    constexpr int LDC = BN + 4;
-    static_assert(BM * LDC * 4 <= sgemm_lds_bytes<P, T, LBUF>(), "epilogue tile must fit the staging LDS");
-    float* Cs = reinterpret_cast<float*>(s_smem);
+    static_assert(BM * (BN + 4) * 4 <= sgemm_lds_bytes<P, T, LBUF>(), "epilogue tile must fit the staging LDS");
     __syncthreads();                                   // everyone is done reading the last K-step's images
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const int row = wm * (TM * 32) + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-          Cs[row * LDC + wn * (TN * 32) + j * 32 + r] = acc[i][j][q];
-        }
-    __syncthreads();
-    constexpr int CH = BN / 8, RPP = NT / CH;          // chunks per row, rows per pass
-    const int ch = tid % CH, rr = tid / CH;
-    const int n = n0 + ch * 8;
-    if (n < N) {
-      typename P::SCol sc;
-      p.s_col(ctx, n, sc);
-      unsigned short* out = p.s_out(ctx);
-#pragma unroll 2
-      for (int row = rr; row < BM; row += RPP) {
-        const int m = m0 + row;
-        if (m >= M) break;
-        typename P::ORow orow;
-        p.o_row(ctx, m, orow);
-        const float4 v0 = *reinterpret_cast<const float4*>(Cs + row * LDC + ch * 8);
-        const float4 v1 = *reinterpret_cast<const float4*>(Cs + row * LDC + ch * 8 + 4);
-        float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-        p.s_finish(ctx, orow, sc, n, v);
-        u32x4_t hi, lo;
-        uint32_t hh, ll;
-        split_pair(v[0], v[1], hh, ll); hi[0] = hh; lo[0] = ll;
-        split_pair(v[2], v[3], hh, ll); hi[1] = hh; lo[1] = ll;
-        split_pair(v[4], v[5], hh, ll); hi[2] = hh; lo[2] = ll;
-        split_pair(v[6], v[7], hh, ll); hi[3] = hh; lo[3] = ll;
-        unsigned short* dst = out + p.s_base(orow) + n;
-        *reinterpret_cast<u32x4_t*>(dst) = hi;
-        *reinterpret_cast<u32x4_t*>(dst + N) = lo;
-        if constexpr (P::MASK_OUT) {
-          // 1 bit per element "hi plane != 0" (the ReLU mask the data gradient of the next layer needs): a byte per
-          // 8 channels instead of a 16-byte read of the hi plane (a full 128-byte line per pixel when C = 32)
-          if (unsigned char* mk = p.s_mask(ctx)) {
-            uint32_t bits = 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              bits |= (hi[j] & 0x7fffu) ? (1u << (2 * j)) : 0u;
-              bits |= (hi[j] & 0x7fff0000u) ? (2u << (2 * j)) : 0u;
-            }
-            mk[(size_t)p.s_pix(orow) * (N >> 3) + (n >> 3)] = (unsigned char)bits;
-          }
-        }
-      }
-    }
+    sgemm_s_epilogue<P, BM, BN, NT, TM, TN>(p, ctx, acc, s_smem, M, N, m0, n0, wm, wn, r, h, tid);
   } else {
     igemm_epilogue<P, T>(p, ctx, acc, M, N, m0, n0, wm, wn, r, h, split);
   }

@@ -111,8 +111,9 @@ def convs_fwd12_supported(IH1, IW1, C1, F1, F2):
 
 
 def convs_set_patch_kernels(enable):
-    """Process-wide: 3x3 stride-2 layers on the LDS-patch kernels (default) or on the im2col kernels only."""
-    call("serl_convs_set_patch_kernels", int(bool(enable)))
+    """Process-wide: 1 (default) = LDS-patch kernels where they fit, 0 = im2col kernels only, 2 = without the wide
+    (4-wave) patch forward, 3 = plus the LDS-DMA ring GEMM for the deep layers (A/B measurements)."""
+    call("serl_convs_set_patch_kernels", int(enable))
 
 
 def convs_dgrad(dzs, wds, xacts, dxs, B, IH, IW, C, KH, KW, stride, F, stream, xact_bits=False):

@@ -229,11 +229,12 @@ def test_convs_fwd_dgrad_wgrad(dev, case):
 
 
 @pytest.mark.parametrize("case", [(3, 63, 63, 32, 64), (2, 64, 63, 32, 64), (3, 31, 31, 64, 128), (2, 29, 32, 64, 128),
-                                  (1, 9, 11, 32, 64)])
+                                  (1, 9, 11, 32, 64), (6, 15, 15, 128, 256), (1, 16, 13, 128, 256), (1, 7, 7, 64, 136)])
 def test_patch_conv_bit_identical_to_im2col(dev, case):
-    """The LDS-patch kernels (csrc/pconv.h) keep the k order and the MFMA sequence of the im2col kernels: outputs,
-    ReLU byte masks and data gradients must be bit-identical, over full and ragged bands, odd/even widths and a row
-    narrower than the lane tile."""
+    """The LDS-patch kernels (csrc/pconv.h) and the LDS-DMA ring GEMM (csrc/sgemm_ring.h, layers with F >= 128) keep the
+    k order and the MFMA sequence of the im2col kernels: outputs, ReLU byte masks and data gradients must be
+    bit-identical, over full and ragged bands / row tiles, odd/even widths, a row narrower than the lane tile and a
+    channel count that is not a multiple of the column tile."""
     ops = _ops()
     B, IH, IW, Cin, F = case
     K, S, G = 3, 2, 3
@@ -257,7 +258,7 @@ def test_patch_conv_bit_identical_to_im2col(dev, case):
                            False, K, K, Cin, F, st)
     out = {}
     try:
-        for mode in (0, 1):
+        for mode in (0, 1, 3):
             ops.convs_set_patch_kernels(mode)
             ys = [torch.full((B * OH * OW * F * 2,), -1, dtype=torch.int16, device=dev) for _ in range(G)]
             rm = [torch.full((B * OH * OW * F // 8,), 0xAA, dtype=torch.uint8, device=dev) for _ in range(G)]
@@ -280,12 +281,13 @@ def test_patch_conv_bit_identical_to_im2col(dev, case):
             out[mode] = (ys, rm, dxs, dxn, dws, dbs)
     finally:
         ops.convs_set_patch_kernels(1)
-    for g in range(G):
-        assert torch.equal(out[0][0][g], out[1][0][g]), f"forward differs, group {g}"
-        assert torch.equal(out[0][1][g], out[1][1][g]), f"ReLU byte mask differs, group {g}"
-        assert torch.equal(out[0][2][g], out[1][2][g]), f"data gradient differs, group {g}"
-        assert torch.equal(out[0][3][g], out[1][3][g]), f"unmasked data gradient differs, group {g}"
-    assert bool((out[1][1][1] == 0xAA).all()), "a NULL mask entry must not be written"
+    for mode in (1, 3):
+        for g in range(G):
+            assert torch.equal(out[0][0][g], out[mode][0][g]), f"forward differs, group {g}, mode {mode}"
+            assert torch.equal(out[0][1][g], out[mode][1][g]), f"ReLU byte mask differs, group {g}, mode {mode}"
+            assert torch.equal(out[0][2][g], out[mode][2][g]), f"data gradient differs, group {g}, mode {mode}"
+            assert torch.equal(out[0][3][g], out[mode][3][g]), f"unmasked data gradient differs, group {g}, mode {mode}"
+        assert bool((out[mode][1][1] == 0xAA).all()), "a NULL mask entry must not be written"
     # the patch weight gradient sums the pixels in another order (one slab per persistent block): same values to fp32
     # summation accuracy, and identical when repeated
     for g in range(G):
