@@ -209,6 +209,13 @@ int serl_tanh_gaussian_fwd(const float* mean, const float* log_std_raw, int ld_m
 int serl_tanh_gaussian_bwd(const float* act, int ld_act, const float* eps, const float* log_std_raw, int ld_ms,
                            const float* da, int ld_da, const float* log_temp, float inv_batch, float* dmean,
                            float* dlstd, int ld_out, int B, int A, void* stream);
+/* behaviour-cloning losses: -mean log_prob of GIVEN actions (clipped to +-(1 - 1e-5), x = atanh(a)) under the tanh-Gaussian
+ * policy with its gradient wrt mean / raw log-std (serl/agents/bc/pixel_bc_learner.py:114-134), info[0] = sum of the
+ * per-row nll; sigmoid BCE of logits against (action column > 0) (pixel_hybrid_bc_learner.py:167-176), info[0] = sum. */
+int serl_tanh_gaussian_nll(const float* mean, const float* log_std_raw, int ld_ms, const float* actions, int ld_act, int B,
+                           int A, float inv_batch, float* dmean, float* dlstd, int ld_out, float* info, void* stream);
+int serl_bce_logits(const float* logits, const float* action_column, int ld_act, int B, float inv_batch, float* dlogit,
+                    float* info, void* stream);
 
 /* ---- TD target (ensemble min, optional entropy backup) + critic loss gradient, serl/agents/sac/sac_learner.py:185-209 */
 int serl_td_loss(const float* next_q, int Emin, const float* rew, const float* mask, const float* next_logp,
@@ -273,6 +280,7 @@ typedef struct {
   int encoder;                 /* 0 TwoD4PGEncoder (trainable conv stack), 1 TwoMobileNetEncoder (frozen backbone, stack 1) */
   int feat_h, feat_w, feat_c;  /* encoder 1: serl_mbv3_feature_shape(height, width) */
   float encoder_dropout;       /* encoder 1: Dropout rate behind the spatial embeddings in training passes (0.1) */
+  int critic_no_action;        /* != 0: the "critic" slot is the hybrid BC learner's discrete actor: MLP on the latent only */
 } serl_learner_config;
 /* flat fp32 device buffers of ONE agent copy (parameters, Adam moments, temperature state {log_temp, mu, nu}) plus the
  * gradient buffers (same layouts); update() steps them in place -- the caller clones first to keep the old agent valid */
@@ -321,6 +329,21 @@ int serl_learner_update(serl_learner* h, const serl_agent_buffers* agent, const 
 int serl_learner_act(serl_learner* h, const float* actor_params, const unsigned char* const* images,
                      const float* state_or_obs, const unsigned* key, int deterministic, float* act_out, float* eps_out,
                      void* stream);
+/* ---- behaviour cloning: PixelBCLearner.update (serl/agents/bc/pixel_bc_learner.py:104-139) and
+ * PixelHybridBCLearner.update / compute_actions (pixel_hybrid_bc_learner.py:123-185).  actor: the TanhNormal policy (actor
+ * layout, its encoder is trained); disc (NULL for PixelBCLearner): the discrete actor in the handle's critic layout
+ * (num_qs = 1, no LayerNorm, critic_no_action = 1).  batch: n, actions (n, ld_actions), state, pixels (observations only;
+ * kind 2 reads .obs).  key_aug / key1 / key2: the augmentation key and the two dropout keys of the call (jax keys, host).
+ * info_out: 2 device floats {sum of per-row nll, sum of per-row BCE}. */
+typedef struct {
+  float *actor, *actor_mu, *actor_nu, *actor_grads, *disc, *disc_mu, *disc_nu, *disc_grads;
+  int actor_step, disc_step;        /* optimizer step counts BEFORE this update */
+} serl_bc_buffers;
+int serl_learner_bc_update(serl_learner* h, const serl_bc_buffers* bc, const serl_update_batch* batch, int ld_actions,
+                           const unsigned* key_aug, const unsigned* key1, const unsigned* key2, float* info_out,
+                           void* stream);
+int serl_learner_bc_logit(serl_learner* h, const float* disc_params, const unsigned char* const* images,
+                          const float* state, float* logit_out, void* stream);
 /* test / tooling access: copy a named workspace buffer of the update at minibatch size B ("aug_<0 obs|1 next>_<cam>") */
 int serl_learner_read_buffer(serl_learner* h, int B, const char* name, void* dst, long long nbytes, void* stream);
 /* device address and size of a named workspace buffer ("bb_<side>_<cam>": the frozen backbone's features of the augmented

@@ -45,6 +45,8 @@ _SIGS = {
     "serl_fill": [c_p, c_f, c_ll, c_p],
     "serl_tanh_gaussian_fwd": [c_p, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_u, c_u, c_i, c_i, c_i, c_p],
     "serl_tanh_gaussian_bwd": [c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_p, c_f, c_p, c_p, c_i, c_i, c_i, c_p],
+    "serl_tanh_gaussian_nll": [c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_f, c_p, c_p, c_i, c_p, c_p],
+    "serl_bce_logits": [c_p, c_p, c_i, c_i, c_f, c_p, c_p, c_p],
     "serl_td_loss": [c_p, c_i, c_p, c_p, c_p, c_p, c_f, c_p, c_i, c_i, c_f, c_p, c_p, c_p, c_p],
     "serl_actor_loss": [c_p, c_i, c_i, c_p, c_p, c_p, c_p],
     "serl_adam_polyak": [c_p, c_p, c_p, c_p, c_p, c_ll, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p],
@@ -79,6 +81,8 @@ _SIGS = {
     "serl_learner_set_backbone": [c_p, c_p],
     "serl_learner_update": [c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i],
     "serl_learner_act": [c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p],
+    "serl_learner_bc_update": [c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p],
+    "serl_learner_bc_logit": [c_p, c_p, c_p, c_p, c_p, c_p],
     "serl_learner_read_buffer": [c_p, c_i, C.c_char_p, c_p, c_ll, c_p],
     "serl_learner_buffer_ptr": [c_p, c_i, C.c_char_p, c_p, c_p],
     "serl_learner_workspace_bytes": [c_p],

@@ -1,4 +1,6 @@
 from .agent import Agent
+from .bc.pixel_bc_learner import PixelBCLearner
+from .bc.pixel_hybrid_bc_learner import PixelHybridBCLearner
 from .ddpg.ddpg_learner import DDPGLearner
 from .ddpg.pixel_ddpg_learner import PixelDDPGLearner
 from .drq.drq_classifier_reward_learner import DrQClassifierRewardLearner
@@ -7,4 +9,4 @@ from .sac.sac_learner import SACLearner
 from .train_state import TempState, TrainState
 from .vice.vice_learner import VICELearner
 
-__all__ = ["Agent", "SACLearner", "DDPGLearner", "PixelDDPGLearner", "DrQLearner", "DrQClassifierRewardLearner", "VICELearner", "TrainState", "TempState"]
+__all__ = ["Agent", "PixelBCLearner", "PixelHybridBCLearner", "SACLearner", "DDPGLearner", "PixelDDPGLearner", "DrQLearner", "DrQClassifierRewardLearner", "VICELearner", "TrainState", "TempState"]

@@ -53,6 +53,7 @@ struct Cfg {
   int aug_rank[MAX_CAM];   // position of (sorted) camera ci in the caller's pixel_keys order: augmentation key order
   float discount, tau, target_entropy, actor_lr, critic_lr, temp_lr;
   int enc_dim, latent, ldz;
+  int crit_A;               // action columns of the critic's input (0: the BC learners' discrete head sees the latent only)
 };
 
 // offsets (in floats) of the leaves of a flat parameter store, in the order serl_amd/networks/spec.py adds them
@@ -571,7 +572,7 @@ int trunk_bwd(serl_learner* h, char tag, const Store& s, const EncOff& eo, const
 int ensemble_fwd(serl_learner* h, char tag, const Store& s, const CriticOff& co, int m0, int mstride, int E,
                  const float* inp, int ld_inp, int B, Workspace& ws, hipStream_t st, bool save, float** q_out) {
   const Cfg& c = h->cfg;
-  int din = c.latent + c.A;
+  int din = c.latent + c.crit_A;
   const int nl = c.nh, hl = c.hid[nl - 1];
   const float* a_ptr = inp; long long a_zs = 0, a_ms = ld_inp;
   WSF(ws, st, q, (size_t)E * B, "q_%c", tag);
@@ -621,7 +622,7 @@ int ensemble_bwd(serl_learner* h, char tag, const Store& s, const CriticOff& co,
   const Cfg& c = h->cfg;
   const int E = c.E, ln = c.ln, nl = c.nh;
   int dims[MAX_HID + 1];
-  dims[0] = c.latent + c.A;
+  dims[0] = c.latent + c.crit_A;
   for (int i = 0; i < nl; ++i) dims[i + 1] = c.hid[i];
   const int hl = dims[nl];
   hipStream_t stw = st;
@@ -714,6 +715,10 @@ int policy_fwd(serl_learner* h, char tag, const Store& s, const ActorOff& ao, co
     g.a_ms = a_ms; g.a_ks = 1; g.b_zs = ao.lk - ao.mk; g.b_ks = A; g.b_ns = 1; g.c_zs = A; g.c_ms = 2 * A;
     g.bias_zs = ao.lb - ao.mb;
     DRV(gemm(g, st));
+  }
+  if (!act) {      // heads only (behaviour cloning: log-prob of given actions, no sample)
+    if (logp_ret) *logp_ret = nullptr;
+    return SERL_OK;
   }
   float* logp = nullptr;
   if (want_logp) {
@@ -894,6 +899,70 @@ int features_bwd(serl_learner* h, char tag, const Store& store, const EncOff& eo
   return SERL_OK;
 }
 
+// Fused frame-stack gather + _unpack + random shift of all n rows of one side (0 obs, 1 next_obs), one kernel per camera
+// (serl/utils/augmentations.py:5-11,44-48; drq_learner.py:131-137).  Crop offsets are keyed by the GLOBAL row index so that
+// rank shards reproduce the single-process stream; keys in the caller's pixel_keys order: key, rng = split(rng)
+// per camera.
+int augment_side(serl_learner* h, const serl_pixel_source* pixels, int side, const uint32_t key_side[2], int n, int utd,
+                 int B, int rank, int world, Workspace& ws, hipStream_t st, Feats& f) {
+  const Cfg& c = h->cfg;
+  const int S = c.stack, pad = 4;   // batched_random_crop(..., padding=4), serl/utils/augmentations.py:44
+  const size_t img = (size_t)c.H * c.W * 3 * S;
+  uint32_t cam_key[MAX_CAM][2], kk[2] = {key_side[0], key_side[1]};
+  for (int p = 0; p < c.ncam; ++p) {
+    uint32_t k[2], r[2];
+    split2(kk, k, r);
+    cam_key[p][0] = k[0]; cam_key[p][1] = k[1];
+    kk[0] = r[0]; kk[1] = r[1];
+  }
+  for (int ci = 0; ci < c.ncam; ++ci) {
+    const uint32_t* key = cam_key[c.aug_rank[ci]];
+    WSB(ws, st, int, off, (size_t)n * 2 * 4, "off_%d_%d", side, ci);
+    if (world == 1) {
+      DRV(serl_crop_offsets(key[0], key[1], n, 0, n, pad, off, st));
+    } else {
+      for (int i = 0; i < utd; ++i)
+        DRV(serl_crop_offsets(key[0], key[1], B, i * B * world + rank * B, n * world, pad, off + 2 * i * B, st));
+    }
+    WSB(ws, st, unsigned char, dst, (size_t)n * img, "aug_%d_%d", side, ci);
+    f.aug[side][ci] = dst;
+    const serl_pixel_source& src = pixels[ci];
+    if (src.kind == 0) {          // device frame store + window indices
+      SERL_CHECK_ARG(src.frames && src.indx, "learner_update: frame store source without frames / indices");
+      DRV(serl_gather_crop_frames(src.frames, src.capacity, src.indx, S + 1, side, off, dst, n, c.H, c.W, S, pad, st));
+    } else if (src.kind == 1) {   // packed (n,H,W,3,S+1)
+      SERL_CHECK_ARG(src.obs, "learner_update: packed source missing");
+      DRV(serl_gather_crop_packed(src.obs, S + 1, side, off, dst, n, c.H, c.W, S, pad, st));
+    } else {                      // unpacked: obs (n,H,W,3,S) and next_obs (n,H,W,3,S)
+      const unsigned char* p = side ? src.next_obs : src.obs;
+      SERL_CHECK_ARG(p, "learner_update: unpacked source missing");
+      DRV(serl_gather_crop_packed(p, S, 0, off, dst, n, c.H, c.W, S, pad, st));
+    }
+  }
+  return SERL_OK;
+}
+
+// The backbone is frozen and the same in every network of the learner (a module attribute, not a parameter:
+// two_mobilenet_encoder.py:12,31), so its features of the augmented images of one side are computed ONCE per call for all
+// n rows; the passes of every step only pool them (trainable SLE kernels).
+int backbone_side(serl_learner* h, int side, int n, Workspace& ws, hipStream_t st, Feats& f) {
+  const Cfg& c = h->cfg;
+  SERL_CHECK_ARG(h->backbone, "learner_update: serl_learner_set_backbone has not been called");
+  const int chunk = std::min(n, 256);
+  const long long wsb = serl_mbv3_workspace_bytes(chunk, c.H, c.W);
+  WSF(ws, st, bbws, (size_t)wsb / 4, "bb_ws");
+  const size_t fsz = (size_t)c.fh * c.fw * c.fc, img1 = (size_t)c.H * c.W * 3;
+  for (int ci = 0; ci < c.ncam; ++ci) {
+    WSF(ws, st, bb, (size_t)n * fsz, "bb_%d_%d", side, ci);
+    f.bb[side][ci] = bb;
+    for (int r0 = 0; r0 < n; r0 += chunk) {
+      const int m = std::min(chunk, n - r0);
+      DRV(serl_mbv3_forward(h->backbone, f.aug[side][ci] + r0 * img1, 1, m, c.H, c.W, bbws, wsb, bb + r0 * fsz, st));
+    }
+  }
+  return SERL_OK;
+}
+
 // REDQ subsample (serl/networks/ensemble.py:25-37) -> first member / member stride when the picked members form an
 // arithmetic sequence (always for 2 of E), else a gathered copy of the members in a scratch store
 int target_members(serl_learner* h, const uint32_t key[2], const Store& target, Workspace& ws, hipStream_t st, int* m0,
@@ -915,7 +984,7 @@ int target_members(serl_learner* h, const uint32_t key[2], const Store& target, 
   const CriticOff& co = h->co;
   WSF(ws, st, scratch, (size_t)co.size, "tgt_scratch");
   int dims[MAX_HID + 1];
-  dims[0] = c.latent + c.A;
+  dims[0] = c.latent + c.crit_A;
   for (int i = 0; i < c.nh; ++i) dims[i + 1] = c.hid[i];
   auto gather = [&](long long off, long long per) -> int {
     for (int j = 0; j < m; ++j)
@@ -987,6 +1056,7 @@ extern "C" int serl_learner_create(const serl_learner_config* pc, const long lon
     c.latent = c.obs_dim;
   }
   c.ldz = c.latent + c.A;
+  c.crit_A = pc->critic_no_action ? 0 : c.A;
   // parameter leaf offsets, in the order serl_amd/networks/spec.py lays the stores out
   auto enc = [&](const long long* o, int n, int* cur, EncOff* e) -> bool {
     const int need = c.ncam * c.nl * 2 + c.ncam + 8;
@@ -1127,64 +1197,11 @@ extern "C" int serl_learner_update(serl_learner* h, const serl_agent_buffers* ag
   if (!c.pixel) SERL_CHECK_ARG(f.obs && f.next_obs, "learner_update: observations missing");
   float* info = info_out;   // 8 floats of the caller: the data-parallel hook all-reduces its first 4
   if (c.pixel) {
-    // fused frame-stack gather + _unpack + random shift of all B*U rows, one kernel per (side, camera); crop offsets
-    // keyed by the GLOBAL row index so that rank shards reproduce the single-process stream
     SERL_CHECK_ARG(f.state && f.next_state, "learner_update: state leaves missing");
-    const int S = c.stack, pad = 4;   // batched_random_crop(..., padding=4), serl/utils/augmentations.py:44
-    const size_t img = (size_t)c.H * c.W * 3 * S;
-    for (int side = 0; side < 2; ++side) {
-      // keys in the caller's pixel_keys order: key, rng = split(rng) per camera (drq_learner.py:131-137)
-      uint32_t cam_key[MAX_CAM][2], kk[2] = {side ? key_next[0] : key_obs[0], side ? key_next[1] : key_obs[1]};
-      for (int p = 0; p < c.ncam; ++p) {
-        uint32_t k[2], r[2];
-        split2(kk, k, r);
-        cam_key[p][0] = k[0]; cam_key[p][1] = k[1];
-        kk[0] = r[0]; kk[1] = r[1];
-      }
-      for (int ci = 0; ci < c.ncam; ++ci) {
-        const uint32_t* key = cam_key[c.aug_rank[ci]];
-        WSB(ws, st, int, off, (size_t)n * 2 * 4, "off_%d_%d", side, ci);
-        if (world == 1) {
-          DRV(serl_crop_offsets(key[0], key[1], n, 0, n, pad, off, st));
-        } else {
-          for (int i = 0; i < utd; ++i)
-            DRV(serl_crop_offsets(key[0], key[1], B, i * B * world + rank * B, n * world, pad, off + 2 * i * B, st));
-        }
-        WSB(ws, st, unsigned char, dst, (size_t)n * img, "aug_%d_%d", side, ci);
-        f.aug[side][ci] = dst;
-        const serl_pixel_source& src = bt->pixels[ci];
-        if (src.kind == 0) {          // device frame store + window indices
-          SERL_CHECK_ARG(src.frames && src.indx, "learner_update: frame store source without frames / indices");
-          DRV(serl_gather_crop_frames(src.frames, src.capacity, src.indx, S + 1, side, off, dst, n, c.H, c.W, S, pad, st));
-        } else if (src.kind == 1) {   // packed (n,H,W,3,S+1)
-          SERL_CHECK_ARG(src.obs, "learner_update: packed source missing");
-          DRV(serl_gather_crop_packed(src.obs, S + 1, side, off, dst, n, c.H, c.W, S, pad, st));
-        } else {                      // unpacked: obs (n,H,W,3,S) and next_obs (n,H,W,3,S)
-          const unsigned char* p = side ? src.next_obs : src.obs;
-          SERL_CHECK_ARG(p, "learner_update: unpacked source missing");
-          DRV(serl_gather_crop_packed(p, S, 0, off, dst, n, c.H, c.W, S, pad, st));
-        }
-      }
-    }
-    if (c.encoder == 1) {
-      // The backbone is frozen and the same in the actor, the critic and the target critic (a module attribute, not a
-      // parameter: two_mobilenet_encoder.py:12,31), so its features of the augmented obs / next_obs images are computed
-      // ONCE per call for all B*U rows; the three passes of every critic step only pool them (trainable SLE kernels).
-      SERL_CHECK_ARG(h->backbone, "learner_update: serl_learner_set_backbone has not been called");
-      const int chunk = std::min(n, 256);
-      const long long wsb = serl_mbv3_workspace_bytes(chunk, c.H, c.W);
-      WSF(ws, st, bbws, (size_t)wsb / 4, "bb_ws");
-      const size_t fsz = (size_t)c.fh * c.fw * c.fc, img1 = (size_t)c.H * c.W * 3;
-      for (int side = 0; side < 2; ++side)
-        for (int ci = 0; ci < c.ncam; ++ci) {
-          WSF(ws, st, bb, (size_t)n * fsz, "bb_%d_%d", side, ci);
-          f.bb[side][ci] = bb;
-          for (int r0 = 0; r0 < n; r0 += chunk) {
-            const int m = std::min(chunk, n - r0);
-            DRV(serl_mbv3_forward(h->backbone, f.aug[side][ci] + r0 * img1, 1, m, c.H, c.W, bbws, wsb, bb + r0 * fsz, st));
-          }
-        }
-    }
+    for (int side = 0; side < 2; ++side)
+      DRV(augment_side(h, bt->pixels, side, side ? key_next : key_obs, n, utd, B, rank, world, ws, st, f));
+    if (c.encoder == 1)
+      for (int side = 0; side < 2; ++side) DRV(backbone_side(h, side, n, ws, st, f));
   }
 
   if (bt->features_hook) {
@@ -1354,6 +1371,115 @@ extern "C" int serl_learner_act(serl_learner* h, const float* actor_params, cons
     WSF(ws, st, eps, (size_t)c.A, "eps_A");
     DRV_HIP(hipMemcpyAsync(eps_out, eps, c.A * sizeof(float), hipMemcpyDeviceToDevice, st));
   }
+  return SERL_OK;
+}
+
+// ================================================================= behaviour cloning
+// One `update` of PixelBCLearner / PixelHybridBCLearner (serl/agents/bc/pixel_bc_learner.py:104-139,
+// pixel_hybrid_bc_learner.py:135-185): random-shift augmentation of the observations with key_aug, then
+//   actor:          nll = -mean log_prob(clip(a)) of the tanh-Gaussian policy, gradients THROUGH the image encoder
+//                   (PixelMultiplexer(stop_gradient=False)), dropout key key1, one Adam step;
+//   discrete actor: (hybrid, bc->disc != NULL) PixelMultiplexer(stop_gradient=True) + MLP + Dense(1) on the same augmented
+//                   observations, sigmoid BCE against (last action column > 0), dropout key key2, one Adam step --
+//                   the handle's "critic" slot describes this network (one member, no LayerNorm, no action input).
+// The continuous policy sees the first action_dim columns of the (n, ld_actions) action rows.  info_out[0] = sum of the
+// per-row nll, info_out[1] = sum of the per-row BCE.  Single rank; everything is enqueued on `stream`.
+extern "C" int serl_learner_bc_update(serl_learner* h, const serl_bc_buffers* bc, const serl_update_batch* bt,
+                                      int ld_actions, const unsigned* key_aug, const unsigned* key1, const unsigned* key2,
+                                      float* info_out, void* stream) {
+  SERL_CHECK_ARG(h && bc && bt && key_aug && key1 && key2 && info_out, "learner_bc_update: null pointer");
+  const Cfg& c = h->cfg;
+  SERL_CHECK_ARG(c.pixel, "learner_bc_update: the BC learners are pixel learners");
+  SERL_CHECK_ARG(bc->actor && bc->actor_mu && bc->actor_nu && bc->actor_grads, "learner_bc_update: actor buffers missing");
+  SERL_CHECK_ARG(bt->n >= 1 && bt->actions && bt->state, "learner_bc_update: actions / state missing");
+  const bool hybrid = bc->disc != nullptr;
+  SERL_CHECK_ARG(!hybrid || (bc->disc_mu && bc->disc_nu && bc->disc_grads && c.E == 1 && !c.ln && c.crit_A == 0),
+                 "learner_bc_update: the discrete actor needs its buffers and a one-member, no-LayerNorm, no-action head");
+  SERL_CHECK_ARG(ld_actions >= c.A + (hybrid ? 1 : 0), "learner_bc_update: action rows of %d columns", ld_actions);
+  const int n = bt->n, A = c.A, ldz = c.ldz;
+  hipStream_t st = (hipStream_t)stream;
+  Workspace& ws = h->ws_update[n];
+  const Store actor{bc->actor}, agr{bc->actor_grads};
+  const uint32_t ka[2] = {key_aug[0], key_aug[1]}, k1[2] = {key1[0], key1[1]}, k2[2] = {key2[0], key2[1]};
+
+  Feats f;
+  f.row0 = 0; f.total_rows = n;
+  f.state = bt->state; f.next_state = bt->state;
+  DRV(augment_side(h, bt->pixels, 0, ka, n, 1, n, 0, 1, ws, st, f));
+  if (c.encoder == 1) DRV(backbone_side(h, 0, n, ws, st, f));
+
+  WSF(ws, st, zA, (size_t)n * ldz, "zA");
+  WSF(ws, st, dms, (size_t)n * 2 * A, "dms");
+  {
+    FPass p{'A', actor, &h->ao.e, 0, zA, st, k1};
+    DRV(features(h, &p, 1, f, 0, n, ws, st, 'A', nullptr, true));
+  }
+  DRV(policy_fwd(h, 'A', actor, h->ao, zA, ldz, n, ws, st, nullptr, 0, n, nullptr, 0, true, false, false, nullptr, nullptr));
+  WSF(ws, st, msA, (size_t)n * 2 * A, "ms_A");
+  DRV(serl_tanh_gaussian_nll(msA, msA + A, 2 * A, bt->actions, ld_actions, n, A, 1.0f / (float)n, dms, dms + A, 2 * A,
+                             info_out, st));
+  float* dzlat = nullptr;
+  DRV(policy_bwd(h, 'A', actor, h->ao, agr, zA, ldz, n, ws, st, true, &dzlat));
+  DRV(features_bwd(h, 'A', actor, h->ao.e, agr, f, 0, n, ws, st, dzlat, c.latent, true, nullptr, 1, 0, k1));
+  float bc1, bc2;
+  bias_corrections(bc->actor_step + 1, &bc1, &bc2);
+  DRV(serl_adam_polyak(actor.base, bc->actor_mu, bc->actor_nu, agr.base, nullptr, h->ao.size, c.actor_lr, ADAM_B1, ADAM_B2,
+                       ADAM_EPS, bc1, bc2, 0.0f, 1.0f, st));
+  if (!hybrid) return SERL_OK;
+
+  const Store disc{bc->disc}, dgr{bc->disc_grads};
+  WSF(ws, st, zC, (size_t)n * ldz, "zC");
+  WSF(ws, st, dq, (size_t)n, "dq");
+  {
+    FPass p{'C', disc, &h->co.e, 0, zC, st, k2};
+    DRV(features(h, &p, 1, f, 0, n, ws, st, 'C', nullptr, true));
+  }
+  float* logits = nullptr;
+  DRV(ensemble_fwd(h, 'C', disc, h->co, 0, 1, 1, zC, ldz, n, ws, st, true, &logits));
+  DRV(serl_bce_logits(logits, bt->actions + A, ld_actions, n, 1.0f / (float)n, dq, info_out + 1, st));
+  float* dinp = nullptr; int nslab = 1; long long ss = 0;
+  DRV(ensemble_bwd(h, 'C', disc, h->co, &dgr, dq, zC, ldz, n, ws, st, nullptr, 1, &dinp, &nslab, &ss));
+  // stop_gradient behind the encoder: trunk gradients only; the encoder leaves of disc_grads stay zero (never written)
+  DRV(features_bwd(h, 'C', disc, h->co.e, dgr, f, 0, n, ws, st, dinp, c.latent, false, nullptr, 1, 0, k2));
+  bias_corrections(bc->disc_step + 1, &bc1, &bc2);
+  return serl_adam_polyak(disc.base, bc->disc_mu, bc->disc_nu, dgr.base, nullptr, h->co.size, c.actor_lr, ADAM_B1, ADAM_B2,
+                          ADAM_EPS, bc1, bc2, 0.0f, 1.0f, st);
+}
+
+// The discrete actor's logit for ONE observation (PixelHybridBCLearner.compute_actions, pixel_hybrid_bc_learner.py:126):
+// encoder + trunk + MLP + Dense(1) with the given parameters, training=False.  logit_out: one device float.
+extern "C" int serl_learner_bc_logit(serl_learner* h, const float* disc_params, const unsigned char* const* images,
+                                     const float* state, float* logit_out, void* stream) {
+  SERL_CHECK_ARG(h && disc_params && images && state && logit_out, "learner_bc_logit: null pointer");
+  std::lock_guard<std::mutex> lock(h->act_mu);
+  const Cfg& c = h->cfg;
+  SERL_CHECK_ARG(c.pixel && c.E == 1 && !c.ln && c.crit_A == 0, "learner_bc_logit: not a hybrid BC learner");
+  hipStream_t st = (hipStream_t)stream;
+  Workspace& ws = h->ws_act;
+  const Store disc{(float*)disc_params};
+  WSF(ws, st, z, (size_t)c.ldz, "zC");
+  if (c.encoder == 1) {
+    SERL_CHECK_ARG(h->backbone, "learner_bc_logit: backbone missing");
+    const long long wsb = serl_mbv3_workspace_bytes(1, c.H, c.W);
+    WSF(ws, st, bbws, (size_t)wsb / 4, "bb_ws");
+    Feats f;
+    f.row0 = 0; f.total_rows = 1;
+    for (int ci = 0; ci < c.ncam; ++ci) {
+      WSF(ws, st, bb, (size_t)c.fh * c.fw * c.fc, "bb_0_%d", ci);
+      DRV(serl_mbv3_forward(h->backbone, images[ci], 1, 1, c.H, c.W, bbws, wsb, bb, st));
+      f.bb[0][ci] = bb;
+    }
+    FPass p{'C', disc, &h->co.e, 0, z, st};
+    DRV(mobilenet_sle_fwd(h, &p, 1, f, 0, 1, ws, st));
+  } else {
+    Pass p; p.tag = 'C'; p.store = disc; p.eo = &h->co.e;
+    for (int ci = 0; ci < c.ncam; ++ci) p.imgs[ci] = images[ci];
+    DRV(encoder_fwd(h, &p, 1, 1, ws, st, 0, true));
+  }
+  DRV(trunk_fwd(h, 'C', disc, h->co.e, state, z, c.ldz, 1, ws, st, false));
+  float* q = nullptr;
+  DRV(ensemble_fwd(h, 'C', disc, h->co, 0, 1, 1, z, c.ldz, 1, ws, st, false, &q));
+  DRV_HIP(hipMemcpyAsync(logit_out, q, sizeof(float), hipMemcpyDeviceToDevice, st));
   return SERL_OK;
 }
 

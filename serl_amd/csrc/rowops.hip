@@ -548,6 +548,69 @@ __device__ float block_sum(float v, float* sh) {
   return s;
 }
 
+// ------------------------------------------------------------------ behaviour-cloning losses
+// nll = -mean_b log_prob(a_b) of the tanh-Gaussian policy for GIVEN actions (serl/agents/bc/pixel_bc_learner.py:114-134,
+// pixel_hybrid_bc_learner.py:145-165): a clipped to [-1 + 1e-5, 1 - 1e-5], x = atanh(a) (TFP Tanh bijector inverse),
+//   log_prob = sum_j [-z^2/2 - ls - log(2 pi)/2] - sum_j 2 (log 2 - x - softplus(-2x)),  z = (x - mu) exp(-ls).
+// dL/dmu = -(z exp(-ls)) / Bg, dL/dls = -(z^2 - 1) / Bg (0 where the raw log-std was clipped).  info[0] = sum_b -log_prob.
+__global__ __launch_bounds__(256) void tanh_gaussian_nll_kernel(const float* mean, const float* lstd, int ld_ms,
+                                                                const float* act, int ld_act, int B, int A,
+                                                                float inv_batch, float* dmean, float* dlstd, int ld_out,
+                                                                float* info) {
+  __shared__ float sh[4];
+  float nll = 0.f;
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    float lp = 0.f;
+    for (int j = 0; j < A; ++j) {
+      const float a = fminf(fmaxf(act[(long long)b * ld_act + j], -1.f + 1e-5f), 1.f - 1e-5f);
+      const float x = atanhf(a);
+      const float mu = mean[(long long)b * ld_ms + j];
+      const float raw = lstd[(long long)b * ld_ms + j];
+      const float ls = fminf(fmaxf(raw, -20.f), 2.f);
+      const float is = expf(-ls), z = (x - mu) * is;
+      lp += (-0.5f * z * z - ls - 0.918938533204672742f) - 2.f * (0.693147180559945309f - x - softplusf(-2.f * x));
+      dmean[(long long)b * ld_out + j] = -z * is * inv_batch;
+      dlstd[(long long)b * ld_out + j] = (raw < -20.f || raw > 2.f) ? 0.f : -(z * z - 1.f) * inv_batch;
+    }
+    nll -= lp;
+  }
+  nll = block_sum(nll, sh);
+  if (threadIdx.x == 0) info[0] = nll;
+}
+extern "C" int serl_tanh_gaussian_nll(const float* mean, const float* log_std_raw, int ld_ms, const float* actions,
+                                      int ld_act, int B, int A, float inv_batch, float* dmean, float* dlstd, int ld_out,
+                                      float* info, void* stream) {
+  SERL_CHECK_ARG(mean && log_std_raw && actions && dmean && dlstd && info && B >= 1 && A >= 1, "tanh_gaussian_nll: bad args");
+  hipLaunchKernelGGL(tanh_gaussian_nll_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, mean, log_std_raw, ld_ms, actions,
+                     ld_act, B, A, inv_batch, dmean, dlstd, ld_out, info);
+  SERL_CHECK_LAUNCH("tanh_gaussian_nll");
+  return SERL_OK;
+}
+
+// optax.sigmoid_binary_cross_entropy(logits, labels).mean() with labels = (a > 0) of one action column
+// (pixel_hybrid_bc_learner.py:167-176): l = -y log_sigmoid(x) - (1 - y) log_sigmoid(-x) = max(x, 0) - x y + log1p(exp(-|x|)),
+// dl/dx = sigmoid(x) - y.  info[0] = sum_b l_b, dlogit = dl/dx / Bg.
+__global__ __launch_bounds__(256) void bce_logits_kernel(const float* logits, const float* act, int ld_act, int B,
+                                                         float inv_batch, float* dlogit, float* info) {
+  __shared__ float sh[4];
+  float l = 0.f;
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    const float x = logits[b], y = act[(long long)b * ld_act] > 0.f ? 1.f : 0.f;
+    l += fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x)));
+    dlogit[b] = (1.f / (1.f + expf(-x)) - y) * inv_batch;
+  }
+  l = block_sum(l, sh);
+  if (threadIdx.x == 0) info[0] = l;
+}
+extern "C" int serl_bce_logits(const float* logits, const float* action_column, int ld_act, int B, float inv_batch,
+                               float* dlogit, float* info, void* stream) {
+  SERL_CHECK_ARG(logits && action_column && dlogit && info && B >= 1, "bce_logits: bad args");
+  hipLaunchKernelGGL(bce_logits_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, action_column, ld_act, B, inv_batch,
+                     dlogit, info);
+  SERL_CHECK_LAUNCH("bce_logits");
+  return SERL_OK;
+}
+
 // ------------------------------------------------------------------ TD target + critic loss gradient
 // target = r + discount*mask*min_e next_q[e] (- discount*mask*alpha*next_logp if backup_entropy)
 // loss = mean_{e,b} (q - target)^2 ; dq = 2 (q - target) * inv_count  (sac_learner.py:185-209)

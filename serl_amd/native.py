@@ -25,7 +25,7 @@ class LearnerConfig(C.Structure):
                 ("cnn_filters", C.c_int * 8), ("cnn_strides", C.c_int * 8), ("aug_rank", C.c_int * 4),
                 ("discount", C.c_float), ("tau", C.c_float), ("target_entropy", C.c_float), ("actor_lr", C.c_float),
                 ("critic_lr", C.c_float), ("temp_lr", C.c_float), ("encoder", C.c_int), ("feat_h", C.c_int),
-                ("feat_w", C.c_int), ("feat_c", C.c_int), ("encoder_dropout", C.c_float)]
+                ("feat_w", C.c_int), ("feat_c", C.c_int), ("encoder_dropout", C.c_float), ("critic_no_action", C.c_int)]
 
 
 class AgentBuffers(C.Structure):
@@ -46,6 +46,11 @@ class UpdateBatch(C.Structure):
                 ("use_sac_rng", C.c_int), ("sac_rng", C.c_uint * 2)]
 
 
+class BcBuffers(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("actor", "actor_mu", "actor_nu", "actor_grads", "disc", "disc_mu", "disc_nu",
+                                          "disc_grads")] + [("actor_step", C.c_int), ("disc_step", C.c_int)]
+
+
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)
 
 KIND_FRAMES, KIND_PACKED, KIND_UNPACKED = 0, 1, 2
@@ -58,7 +63,7 @@ def _offsets(layout):
 
 class NativeLearner:
     def __init__(self, cfg: NetConfig, *, num_min_qs, backup_entropy, has_temperature, discount, tau, target_entropy,
-                 actor_lr, critic_lr, temp_lr):
+                 actor_lr, critic_lr, temp_lr, critic_layout_fn=critic_layout, critic_no_action=False):
         if len(cfg.hidden_dims) > 4:
             raise ValueError("at most 4 hidden layers")
         lc = LearnerConfig()
@@ -83,7 +88,8 @@ class NativeLearner:
                 lc.aug_rank[ci] = cfg.pixel_keys.index(cam)
         lc.discount, lc.tau, lc.target_entropy = float(discount), float(tau), float(target_entropy)
         lc.actor_lr, lc.critic_lr, lc.temp_lr = float(actor_lr or 0.0), float(critic_lr or 0.0), float(temp_lr or 0.0)
-        co, nco = _offsets(critic_layout(cfg))
+        lc.critic_no_action = int(bool(critic_no_action))      # hybrid BC: the "critic" slot is the discrete actor
+        co, nco = _offsets(critic_layout_fn(cfg))
         ao, nao = _offsets(actor_layout(cfg))
         h = C.c_void_p()
         _lib.call("serl_learner_create", C.byref(lc), co, nco, ao, nao, C.byref(h))
@@ -135,6 +141,16 @@ class NativeLearner:
             raise err[0]
         _lib.check(status, "serl_learner_update")
         return np.array([rout[0], rout[1]], dtype=np.uint32)
+
+    # ------------------------------------------------------------------ behaviour cloning
+    def bc_update(self, buffers: "BcBuffers", batch: UpdateBatch, ld_actions, key_aug, key1, key2, info_out, stream):
+        ks = [(C.c_uint * 2)(int(k[0]), int(k[1])) for k in (key_aug, key1, key2)]
+        _lib.call("serl_learner_bc_update", self._h, C.byref(buffers), C.byref(batch), int(ld_actions), ks[0], ks[1], ks[2],
+                  info_out, stream)
+
+    def bc_logit(self, disc_params_ptr, images, state_ptr, out_ptr, stream):
+        imgs = (C.c_void_p * len(images))(*images)
+        _lib.call("serl_learner_bc_logit", self._h, disc_params_ptr, imgs, state_ptr, out_ptr, stream)
 
     # ------------------------------------------------------------------ acting
     def act(self, actor_params_ptr, images, state_or_obs_ptr, key, deterministic, act_out_ptr, eps_out_ptr, stream):

@@ -130,6 +130,23 @@ def critic_layout(cfg: NetConfig) -> Layout:
     return lay
 
 
+def discrete_actor_layout(cfg: NetConfig) -> Layout:
+    """PixelMultiplexer(stop_gradient=True) -> OneDimOutput(MLP) -> Dense(1): the gripper head of PixelHybridBCLearner
+    (serl/agents/bc/pixel_hybrid_bc_learner.py:91-106, serl/networks/one_d_output.py:7-21).  Same memory order as a
+    one-member critic without LayerNorm and without the action input (the driver's "critic" slot)."""
+    lay = Layout()
+    _add_encoder_and_trunk(lay, cfg)
+    pre = ("OneDimOutput_0",)
+    din = cfg.latent
+    for i, h in enumerate(cfg.hidden_dims):
+        lay.add(pre + ("MLP_0", f"Dense_{i}", "kernel"), (din, h))
+        lay.add(pre + ("MLP_0", f"Dense_{i}", "bias"), (h,))
+        din = h
+    lay.add(pre + ("Dense_0", "kernel"), (din, 1))
+    lay.add(pre + ("Dense_0", "bias"), (1,))
+    return lay
+
+
 def actor_layout(cfg: NetConfig) -> Layout:
     lay = Layout()
     if cfg.pixel:

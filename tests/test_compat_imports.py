@@ -14,6 +14,7 @@ LEARNER_SIDE_IMPORTS = [
     "from serl.agents import DrQLearner",
     "from serl.agents import DDPGLearner",
     "from serl.agents import PixelDDPGLearner",
+    "from serl.agents import PixelBCLearner, PixelHybridBCLearner",
     "from serl.data import ReplayBuffer, MemoryEfficientReplayBuffer",
     "from serl.data import GPUReplayBuffer",
     "from serl.utils.commons import get_data, restore_checkpoint_, ema",
