@@ -209,6 +209,18 @@ int serl_tanh_gaussian_fwd(const float* mean, const float* log_std_raw, int ld_m
 int serl_tanh_gaussian_bwd(const float* act, int ld_act, const float* eps, const float* log_std_raw, int ld_ms,
                            const float* da, int ld_da, const float* log_temp, float inv_batch, float* dmean,
                            float* dlstd, int ld_out, int B, int A, void* stream);
+/* Ensemble(StateActionValue(MLP)) forward with hidden dims (256, 256) in ONE launch (csrc/ensemble.hip; serl/networks/
+ * ensemble.py:8-22, state_action_value.py:11-19, mlp.py:18-35): Dense -> [LayerNorm] -> ReLU twice, then the Dense(1) head.
+ * Member e's leaves sit e * stride floats behind the given pointers (a negative stride walks a REDQ subsample backwards).
+ * h0 / h1 (post-ReLU activations), xh0 / xh1 / rs0 / rs1 (LayerNorm x-hat and 1/sigma) are what the backward reads; all
+ * six may be NULL for passes nobody differentiates.  Bit-identical to serl_gemm + serl_ln_act_fwd + serl_ln_act_head_fwd
+ * (or serl_rowdot); precision "bf16_3x" only. */
+int serl_ensemble_fwd_fused(const float* inp, int ld_inp, int din, int B, int E, const float* w0, const float* b0,
+                            const float* g0, const float* be0, const float* w1, const float* b1, const float* g1,
+                            const float* be1, const float* hw, const float* hb, long long w0_member_stride,
+                            long long w1_member_stride, long long vec_member_stride, long long head_bias_member_stride,
+                            int use_ln, float* h0, float* h1, float* xh0, float* xh1, float* rs0, float* rs1, float* q,
+                            void* stream);
 /* behaviour-cloning losses: -mean log_prob of GIVEN actions (clipped to +-(1 - 1e-5), x = atanh(a)) under the tanh-Gaussian
  * policy with its gradient wrt mean / raw log-std (serl/agents/bc/pixel_bc_learner.py:114-134), info[0] = sum of the
  * per-row nll; sigmoid BCE of logits against (action column > 0) (pixel_hybrid_bc_learner.py:167-176), info[0] = sum. */

@@ -47,6 +47,7 @@ _SIGS = {
     "serl_tanh_gaussian_bwd": [c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_p, c_f, c_p, c_p, c_i, c_i, c_i, c_p],
     "serl_tanh_gaussian_nll": [c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_f, c_p, c_p, c_i, c_p, c_p],
     "serl_bce_logits": [c_p, c_p, c_i, c_i, c_f, c_p, c_p, c_p],
+    "serl_ensemble_fwd_fused": [c_p, c_i, c_i, c_i, c_i] + [c_p] * 10 + [c_ll] * 4 + [c_i] + [c_p] * 8,
     "serl_td_loss": [c_p, c_i, c_p, c_p, c_p, c_p, c_f, c_p, c_i, c_i, c_f, c_p, c_p, c_p, c_p],
     "serl_actor_loss": [c_p, c_i, c_i, c_p, c_p, c_p, c_p],
     "serl_adam_polyak": [c_p, c_p, c_p, c_p, c_p, c_ll, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p],

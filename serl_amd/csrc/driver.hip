@@ -162,6 +162,7 @@ struct serl_learner {
   // instrumentation
   bool timing = false, phases = false;
   int wg_main_layers = getenv("SERL_AMD_WG_MAIN_LAYERS") ? atoi(getenv("SERL_AMD_WG_MAIN_LAYERS")) : 1;   // A/B switch
+  bool ens_fused = getenv("SERL_AMD_ENS_FUSED") == nullptr || strcmp(getenv("SERL_AMD_ENS_FUSED"), "0") != 0;   // A/B switch
   bool fuse12 = getenv("SERL_AMD_CONV_FUSE12") == nullptr || strcmp(getenv("SERL_AMD_CONV_FUSE12"), "0") != 0;   // A/B switch
   std::vector<TimeRec> trecs;
   std::vector<PhaseRec> precs;
@@ -578,6 +579,29 @@ int ensemble_fwd(serl_learner* h, char tag, const Store& s, const CriticOff& co,
   WSF(ws, st, q, (size_t)E * B, "q_%c", tag);
   const float* head_w = s.at(co.hk) + (long long)m0 * hl;
   const float* head_b = s.at(co.hb) + m0;
+  if (h->ens_fused && nl == 2 && c.hid[0] == 256 && c.hid[1] == 256 && serl_get_matmul_precision() == 1) {
+    // the whole pass in one launch (ensemble.hip): four dependent launches less on a latency-bound chain
+    float *h0 = nullptr, *h1 = nullptr, *xh0 = nullptr, *xh1 = nullptr, *rs0 = nullptr, *rs1 = nullptr;
+    if (save) {
+      WSF(ws, st, a0, (size_t)E * B * 256, "h0_%c", tag); h0 = a0;
+      WSF(ws, st, a1, (size_t)E * B * 256, "h1_%c", tag); h1 = a1;
+      if (c.ln) {
+        WSF(ws, st, x0, (size_t)E * B * 256, "exh0_%c", tag); xh0 = x0;
+        WSF(ws, st, x1, (size_t)E * B * 256, "exh1_%c", tag); xh1 = x1;
+        WSF(ws, st, r0, (size_t)E * B, "ers0_%c", tag); rs0 = r0;
+        WSF(ws, st, r1, (size_t)E * B, "ers1_%c", tag); rs1 = r1;
+      }
+    }
+    const long long v = 256;
+    DRV(serl_ensemble_fwd_fused(inp, ld_inp, din, B, E, s.at(co.w[0]) + (long long)m0 * din * 256, s.at(co.b[0]) + m0 * v,
+                                c.ln ? s.at(co.lns[0]) + m0 * v : nullptr, c.ln ? s.at(co.lnb[0]) + m0 * v : nullptr,
+                                s.at(co.w[1]) + (long long)m0 * 256 * 256, s.at(co.b[1]) + m0 * v,
+                                c.ln ? s.at(co.lns[1]) + m0 * v : nullptr, c.ln ? s.at(co.lnb[1]) + m0 * v : nullptr, head_w,
+                                head_b, (long long)mstride * din * 256, (long long)mstride * 256 * 256, mstride * v, mstride,
+                                c.ln, h0, h1, xh0, xh1, rs0, rs1, q, st));
+    *q_out = q;
+    return SERL_OK;
+  }
   for (int i = 0; i < nl; ++i) {
     const int hd = c.hid[i];
     const float* W = s.at(co.w[i]) + (long long)m0 * din * hd;
@@ -1209,7 +1233,7 @@ extern "C" int serl_learner_update(serl_learner* h, const serl_agent_buffers* ag
     DRV(allreduce(allreduce_ctx, 3));
   }
   WSF(ws, st, zA, (size_t)B * ldz, "zA");
-  WSF(ws, st, zC, (size_t)B * ldz, "zC");
+  WSF(ws, st, zC1, (size_t)B * ldz, "zC");
   WSF(ws, st, zP, (size_t)B * ldz, "zC_pi");                    // critic input of the actor step
   WSF(ws, st, zT_all, (size_t)utd * B * ldz, "zT_all");         // per-step inputs of the target ensemble
   WSF(ws, st, nlogp_all, (size_t)utd * B, "nlogp_all");
@@ -1224,7 +1248,22 @@ extern "C" int serl_learner_update(serl_learner* h, const serl_agent_buffers* ag
 
   // ---- the actor's no-grad pass over next_obs runs one step ahead on its own stream (constant parameters in the loop)
   DRV(link(st, sta, h->astart));
+  // State-based learners: the "feature stage" is a copy of the observation rows.  The policy reads them in place, and the
+  // critic / target inputs [obs | action] of ALL utd minibatches are assembled by three launches here instead of four
+  // per critic step (every launch costs ~10 us of a ~200 us step on this latency-bound chain).
+  float* zC_all = nullptr;
+  if (!c.pixel) {
+    WSF(ws, st, zc, (size_t)n * ldz, "zC_all");
+    zC_all = zc;
+    DRV(serl_copy2d(zT_all, ldz, f.next_obs, c.obs_dim, n, c.obs_dim, st));
+    DRV(serl_copy2d(zC_all, ldz, f.obs, c.obs_dim, n, c.obs_dim, st));
+    DRV(serl_copy2d(zC_all + c.latent, ldz, bt->actions, A, n, A, st));
+  }
   auto enqueue_actor = [&](int j) -> int {
+    if (!c.pixel)
+      return policy_fwd(h, 'A', actor, ao, f.next_obs + (size_t)j * B * c.obs_dim, c.obs_dim, B, ws, sta, &step_keys[8 * j],
+                        rank * B, Bg, zT_all + ((size_t)j * B * ldz + c.latent), ldz, false, false, c.backup_entropy != 0,
+                        nlogp_all + (size_t)j * B, nullptr);
     FPass p{'A', actor, &ao.e, 1, zA, sta};
     DRV(features(h, &p, 1, f, j * B, B, ws, sta, 0, nullptr, j == 0));   // S-format weight copies made once (j == 0)
     DRV(policy_fwd(h, 'A', actor, ao, zA, ldz, B, ws, sta, &step_keys[8 * j], rank * B, Bg,
@@ -1234,6 +1273,9 @@ extern "C" int serl_learner_update(serl_learner* h, const serl_agent_buffers* ag
     return SERL_OK;
   };
   auto enqueue_actor_obs = [&]() -> int {   // behind the last pass: the actor's own pass over obs for the actor step
+    if (!c.pixel)
+      return policy_fwd(h, 'A', actor, ao, f.obs + (size_t)(utd - 1) * B * c.obs_dim, c.obs_dim, B, ws, sta, key_pi, rank * B,
+                        Bg, zP + c.latent, ldz, false, true, true, logpA, nullptr);
     FPass p{'A', actor, &ao.e, 0, zA, sta};
     DRV(features(h, &p, 1, f, (utd - 1) * B, B, ws, sta, 'A', nullptr, false));
     DRV(policy_fwd(h, 'A', actor, ao, zA, ldz, B, ws, sta, key_pi, rank * B, Bg, zP + c.latent, ldz, false, true, true, logpA,
@@ -1252,7 +1294,8 @@ extern "C" int serl_learner_update(serl_learner* h, const serl_agent_buffers* ag
     Store tstore;
     DRV(target_members(h, &step_keys[8 * i + 2], target, ws, st, &m0, &mstride, &emin, &tstore));
     float* zT = zT_all + (size_t)i * B * ldz;
-    {
+    float* zC = c.pixel ? zC1 : zC_all + (size_t)lo * ldz;
+    if (c.pixel) {
       // target chain on the main stream, critic chain on a side stream, next action from the actor stream
       FPass ps[2] = {{'T', target, &co.e, 1, zT, st, &step_keys[8 * i + 4]}, {'C', critic, &co.e, 0, zC, s1, &step_keys[8 * i + 6]}};
       DRV(features(h, ps, 2, f, lo, B, ws, st, 'C', h->fork_ev, true));
@@ -1265,7 +1308,7 @@ extern "C" int serl_learner_update(serl_learner* h, const serl_agent_buffers* ag
     if (sta != st) DRV_HIP(hipStreamWaitEvent(st, h->adone[i], 0));
     float *next_q, *q;
     DRV(ensemble_fwd(h, 'T', tstore, co, m0, mstride, emin, zT, ldz, B, ws, st, false, &next_q));
-    DRV(serl_copy2d(zC + c.latent, ldz, bt->actions + (size_t)lo * A, A, B, A, s1));
+    if (c.pixel) DRV(serl_copy2d(zC + c.latent, ldz, bt->actions + (size_t)lo * A, A, B, A, s1));
     DRV(ensemble_fwd(h, 'C', critic, co, 0, 1, E, zC, ldz, B, ws, s1, true, &q));
     DRV(link(s1, st, h->join1));
     DRV(serl_td_loss(next_q, emin, bt->rewards + lo, bt->masks + lo, c.backup_entropy ? nlogp_all + (size_t)i * B : nullptr,
@@ -1309,7 +1352,8 @@ extern "C" int serl_learner_update(serl_learner* h, const serl_agent_buffers* ag
   DRV(serl_tanh_gaussian_bwd(zP + c.latent, ldz, epsA, msA + A, 2 * A, dinp + c.latent, ldz, log_temp, 1.0f / Bg, dms,
                              dms + A, 2 * A, B, A, st));
   float* dzlat = nullptr;
-  DRV(policy_bwd(h, 'A', actor, ao, agr, zA, ldz, B, ws, st, c.pixel != 0, &dzlat));
+  if (c.pixel) DRV(policy_bwd(h, 'A', actor, ao, agr, zA, ldz, B, ws, st, true, &dzlat));
+  else DRV(policy_bwd(h, 'A', actor, ao, agr, f.obs + (size_t)lo * c.obs_dim, c.obs_dim, B, ws, st, false, &dzlat));
   DRV(features_bwd(h, 'A', actor, ao.e, agr, f, lo, B, ws, st, dzlat, c.latent, false, nullptr, 1, 0));
   if (world > 1) {
     DRV(allreduce(allreduce_ctx, 1));   // actor gradient
