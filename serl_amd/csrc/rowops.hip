@@ -347,22 +347,25 @@ struct ColSumArgs {
   const float* x2; const float* mul2; float* out2;
   int rows_per_group, N, ldx; long long out_gs;
 };
+// The optional operands are template flags: a load behind a runtime condition makes hipcc branch around it and wait for
+// every load separately, which turns the 16-row loop into 16 dependent memory round trips.
+template <bool W, bool MUL, bool X1, bool X2>
 __global__ __launch_bounds__(256) void colsum_kernel(const ColSumArgs a) {
   __shared__ float red[3][16][17];
   const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
   const int n = blockIdx.x * 16 + cl, e = blockIdx.y;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f;
   if (n < a.N) {
-#pragma unroll 4
+#pragma unroll 8
     for (int r = rl; r < a.rows_per_group; r += 16) {
       const long long row = (long long)e * a.rows_per_group + r;
       const long long i = row * a.ldx + n;
       float v = a.x0[i];
-      if (a.w) v *= a.w[row];
-      if (a.mul) v *= a.mul[i];
+      if constexpr (W) v *= a.w[row];
+      if constexpr (MUL) v *= a.mul[i];
       s0 += v;
-      if (a.x1) s1 += a.x1[i];
-      if (a.x2) s2 += a.x2[i] * a.mul2[i];
+      if constexpr (X1) s1 += a.x1[i];
+      if constexpr (X2) s2 += a.x2[i] * a.mul2[i];
     }
   }
   red[0][rl][cl] = s0; red[1][rl][cl] = s1; red[2][rl][cl] = s2;
@@ -383,7 +386,18 @@ extern "C" int serl_colsum(const float* x0, const float* w, const float* mul, fl
   SERL_CHECK_ARG((x1 != nullptr) == (out1 != nullptr), "colsum: x1/out1 mismatch");
   SERL_CHECK_ARG((x2 != nullptr) == (out2 != nullptr) && (!x2 || mul2), "colsum: x2/mul2/out2 mismatch");
   ColSumArgs a{x0, w, mul, out0, x1, out1, x2, mul2, out2, rows_per_group, N, ldx, out_group_stride};
-  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 16), ngroups), dim3(256), 0, (hipStream_t)stream, a);
+  const dim3 grid(cdiv(N, 16), ngroups);
+  hipStream_t st = (hipStream_t)stream;
+#define COLSUM_CASE(W_, M_, X1_, X2_)                                                                                    \
+  if ((w != nullptr) == W_ && (mul != nullptr) == M_ && (x1 != nullptr) == X1_ && (x2 != nullptr) == X2_)                \
+    hipLaunchKernelGGL((colsum_kernel<W_, M_, X1_, X2_>), grid, dim3(256), 0, st, a);
+  COLSUM_CASE(false, false, false, false) COLSUM_CASE(false, false, false, true) COLSUM_CASE(false, false, true, false)
+  COLSUM_CASE(false, false, true, true) COLSUM_CASE(false, true, false, false) COLSUM_CASE(false, true, false, true)
+  COLSUM_CASE(false, true, true, false) COLSUM_CASE(false, true, true, true) COLSUM_CASE(true, false, false, false)
+  COLSUM_CASE(true, false, false, true) COLSUM_CASE(true, false, true, false) COLSUM_CASE(true, false, true, true)
+  COLSUM_CASE(true, true, false, false) COLSUM_CASE(true, true, false, true) COLSUM_CASE(true, true, true, false)
+  COLSUM_CASE(true, true, true, true)
+#undef COLSUM_CASE
   SERL_CHECK_LAUNCH("colsum");
   return SERL_OK;
 }
