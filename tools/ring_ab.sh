@@ -4,8 +4,8 @@ set -e
 L=serl_amd/csrc
 for v in "" ${1:-}; do
   s=${v:+_$v}
-  for m in ${MODES:-2 1}; do
-    echo "== lib$s BENCH_PATCH=$m (2: im2col kernel for layers 3-4, 1: ring kernel)"
+  for m in ${MODES:-2 1 3}; do
+    echo "== lib$s BENCH_PATCH=$m (2: im2col kernels for layers 3-4, 1: wide patch kernel for conv3, 3: + ring GEMM for conv4)"
     SERL_AMD_LIB=$L/libserl_hip$s.so BENCH_PATCH=$m BENCH_FWD_G=${G:-4} BENCH_ONLY="conv3 fwd,conv4 fwd" timeout -k 10 100 python tools/bench_conv.py 2>/dev/null | grep conv
   done
 done
