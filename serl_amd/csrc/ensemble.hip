@@ -19,12 +19,14 @@ namespace {
 constexpr int EH = 256;                  // hidden width (both layers)
 constexpr int EBM = 32;                  // rows per block
 constexpr int EBK = 32;                  // K slab
+constexpr int ENW = 8, ENT = 64 * ENW;   // waves / threads per block: wave w owns output columns [32 w, 32 w + 32)
+constexpr int ENR = EBM / ENW;           // rows per wave in the LayerNorm phases
 constexpr int E_LDKW_X = (EBK + 8) / 2;  // dwords per row of the x slab image   [row][k]
 constexpr int E_LDKW_H = (EH + 8) / 2;   // dwords per row of the h0 image       [row][k = 256]
 constexpr int E_LDW = EH + 4;            // dwords per k-pair row of the weight slab image [k/2][n]
 constexpr int E_XPART = EBM * E_LDKW_X, E_HPART = EBM * E_LDKW_H, E_WPART = (EBK / 2) * E_LDW;
 constexpr int E_LDC = EH + 4;            // floats per row of the fp32 tile
-constexpr int E_LDS = (2 * E_XPART + 2 * E_HPART + 2 * E_WPART + EBM * E_LDC) * 4;
+constexpr int E_LDS = (4 * E_XPART + 2 * E_HPART + 4 * E_WPART + EBM * E_LDC) * 4;   // two x / weight slab buffers
 
 __device__ __forceinline__ float ens_wave_sum(float v) {
 #pragma unroll
@@ -41,65 +43,61 @@ struct EnsFwdArgs {
   float* q;                                                          // (E, B)
 };
 
-// weight slab [k0, k0 + 32) x 256 of a row-major [K][256] kernel -> registers (k pair kp + 4 i, columns n4 .. n4 + 3)
-struct WRegs { float4 v[4][2]; };
+// weight slab [k0, k0 + 32) x 256 of a row-major [K][256] kernel -> registers (k pair kp + 4 i, columns n4 .. n4 + 3).
+// Loads are unconditional from a clamped row and stay RAW in the registers; rows past K are zeroed when the slab is
+// written to LDS (ens_wstore) -- a select or multiply right behind the load would make the wave wait for it at once, and a
+// load behind a runtime condition makes hipcc branch around it and wait for every one separately.
+struct WRegs { float4 v[2][2]; };   // 8 waves: k pairs kp + 8 i (i < 2), columns n4 .. n4 + 3
 __device__ __forceinline__ void ens_wload(const float* w, int K, int k0, int kp, int n4, WRegs& r) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-      // unconditional load from a clamped row, zeroed afterwards: a load behind a runtime condition makes hipcc branch
-      // around it and wait for each one separately (one memory round trip per element)
-      const int k = k0 + 2 * (kp + 4 * i) + e;
-      const float4 v = *reinterpret_cast<const float4*>(w + (long long)min(k, K - 1) * EH + n4);
-      const float m = k < K ? 1.f : 0.f;
-      r.v[i][e] = make_float4(v.x * m, v.y * m, v.z * m, v.w * m);
+      const int k = k0 + 2 * (kp + 8 * i) + e;
+      r.v[i][e] = *reinterpret_cast<const float4*>(w + (long long)min(k, K - 1) * EH + n4);
     }
 }
-__device__ __forceinline__ void ens_wstore(uint32_t* img, int kp, int n4, const WRegs& r) {
+__device__ __forceinline__ void ens_wstore(uint32_t* img, int K, int k0, int kp, int n4, const WRegs& r) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < 2; ++i) {
+    const int k = k0 + 2 * (kp + 8 * i);
+    const float m0 = k < K ? 1.f : 0.f, m1 = k + 1 < K ? 1.f : 0.f;
     uint32_t hi[4], lo[4];
-    split_pair(r.v[i][0].x, r.v[i][1].x, hi[0], lo[0]);
-    split_pair(r.v[i][0].y, r.v[i][1].y, hi[1], lo[1]);
-    split_pair(r.v[i][0].z, r.v[i][1].z, hi[2], lo[2]);
-    split_pair(r.v[i][0].w, r.v[i][1].w, hi[3], lo[3]);
-    uint32_t* d = img + (kp + 4 * i) * E_LDW + n4;
+    split_pair(r.v[i][0].x * m0, r.v[i][1].x * m1, hi[0], lo[0]);
+    split_pair(r.v[i][0].y * m0, r.v[i][1].y * m1, hi[1], lo[1]);
+    split_pair(r.v[i][0].z * m0, r.v[i][1].z * m1, hi[2], lo[2]);
+    split_pair(r.v[i][0].w * m0, r.v[i][1].w * m1, hi[3], lo[3]);
+    uint32_t* d = img + (kp + 8 * i) * E_LDW + n4;
     *reinterpret_cast<uint4*>(d) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
     *reinterpret_cast<uint4*>(d + E_WPART) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
   }
 }
 
-// one K slab: A fragments from a k-contiguous image (ldkw dwords per row, slab at dword offset a_k0 / 2), B fragments
-// from the weight slab image; wave wn owns columns [64 wn, 64 wn + 64)
+// one K slab: A fragments from a k-contiguous image (ldkw dwords per row, slab at dword offset a_kdw), B fragments from the
+// weight slab image; wave wn owns columns [32 wn, 32 wn + 32)
 __device__ __forceinline__ void ens_mma(const uint32_t* ah_img, int a_part, int ldkw, int a_kdw, const uint32_t* w_img, int wn,
-                                        int r, int h, f32x16 (&acc)[2]) {
+                                        int r, int h, f32x16& acc) {
 #pragma unroll
   for (int s = 0; s < EBK / 16; ++s) {
     const uint4 qa = *reinterpret_cast<const uint4*>(ah_img + r * ldkw + a_kdw + s * 8 + h * 4);
     const uint4 ql = *reinterpret_cast<const uint4*>(ah_img + a_part + r * ldkw + a_kdw + s * 8 + h * 4);
     const bf16x8_t ah = __builtin_bit_cast(bf16x8_t, qa), al = __builtin_bit_cast(bf16x8_t, ql);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const uint32_t* d = w_img + (s * 8 + h * 4) * E_LDW + wn * 64 + j * 32 + r;
-      const bf16x8_t bh = __builtin_bit_cast(bf16x8_t, make_uint4(d[0], d[E_LDW], d[2 * E_LDW], d[3 * E_LDW]));
-      const uint32_t* dl = d + E_WPART;
-      const bf16x8_t bl = __builtin_bit_cast(bf16x8_t, make_uint4(dl[0], dl[E_LDW], dl[2 * E_LDW], dl[3 * E_LDW]));
-      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[j], 0, 0, 0);
-      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[j], 0, 0, 0);
-      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[j], 0, 0, 0);
-    }
+    const uint32_t* d = w_img + (s * 8 + h * 4) * E_LDW + wn * 32 + r;
+    const bf16x8_t bh = __builtin_bit_cast(bf16x8_t, make_uint4(d[0], d[E_LDW], d[2 * E_LDW], d[3 * E_LDW]));
+    const uint32_t* dl = d + E_WPART;
+    const bf16x8_t bl = __builtin_bit_cast(bf16x8_t, make_uint4(dl[0], dl[E_LDW], dl[2 * E_LDW], dl[3 * E_LDW]));
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
   }
 }
 
-__device__ __forceinline__ void ens_acc_to_tile(float* Cs, int wn, int r, int h, const f32x16 (&acc)[2]) {
+__device__ __forceinline__ void ens_acc_to_tile(float* Cs, int wn, int r, int h, const f32x16& acc) {
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
-#pragma unroll
-    for (int q = 0; q < 16; ++q) Cs[((q & 3) + 8 * (q >> 2) + 4 * h) * E_LDC + wn * 64 + j * 32 + r] = acc[j][q];
+  for (int q = 0; q < 16; ++q) Cs[((q & 3) + 8 * (q >> 2) + 4 * h) * E_LDC + wn * 32 + r] = acc[q];
 }
 
-// rows [8 wid, 8 wid + 8) of the fp32 tile: bias, LayerNorm, ReLU exactly as ln_act_fwd_kernel (lane handles columns
+// rows [4 wid, 4 wid + 4) of the fp32 tile: bias, LayerNorm, ReLU exactly as ln_act_fwd_kernel (lane handles columns
 // lane + 64 i); y to HBM (hout) and / or to the bf16 hi / lo image of the next layer (himg); head: q = y . hw + hb
 __device__ __forceinline__ void ens_ln_rows(const float* Cs, int wid, int lane, int row_base, int B, const float* bias,
                                             const float* gamma, const float* beta, int use_ln, float* hout, float* xhout,
@@ -113,12 +111,12 @@ __device__ __forceinline__ void ens_ln_rows(const float* Cs, int wid, int lane, 
     be[i] = use_ln ? beta[n] : 0.f;
     hv[i] = hw ? hw[n] : 0.f;
   }
-  // the 8 rows of the wave are independent: their reductions are issued together so that the cross-lane steps of one
+  // the rows of the wave are independent: their reductions are issued together so that the cross-lane steps of one
   // row hide behind those of the others (a rolled row loop is a chain of ~18 dependent shuffles per row)
-  float z[8][4], s1[8], s2[8];
+  float z[ENR][4], s1[ENR], s2[ENR];
 #pragma unroll
-  for (int rr = 0; rr < 8; ++rr) {
-    const int row = wid * 8 + rr;
+  for (int rr = 0; rr < ENR; ++rr) {
+    const int row = wid * ENR + rr;
     s1[rr] = 0.f; s2[rr] = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -128,31 +126,31 @@ __device__ __forceinline__ void ens_ln_rows(const float* Cs, int wid, int lane, 
       z[rr][i] = v; s1[rr] += v; s2[rr] += v * v;
     }
   }
-  float mean[8], mul[8];
+  float mean[ENR], mul[ENR];
   if (use_ln) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1)
 #pragma unroll
-      for (int rr = 0; rr < 8; ++rr) {
+      for (int rr = 0; rr < ENR; ++rr) {
         s1[rr] += __shfl_xor(s1[rr], o);
         s2[rr] += __shfl_xor(s2[rr], o);
       }
   }
 #pragma unroll
-  for (int rr = 0; rr < 8; ++rr) {
+  for (int rr = 0; rr < ENR; ++rr) {
     mean[rr] = 0.f; mul[rr] = 1.f;
     if (use_ln) {
       mean[rr] = s1[rr] / (float)EH;
       const float var = fmaxf(s2[rr] / (float)EH - mean[rr] * mean[rr], 0.f);
       mul[rr] = rsqrtf(var + ENS_LN_EPS);
-      const int grow = row_base + wid * 8 + rr;
+      const int grow = row_base + wid * ENR + rr;
       if (rsout && lane == 0 && grow < B) rsout[grow] = mul[rr];
     }
   }
-  float dot[8];
+  float dot[ENR];
 #pragma unroll
-  for (int rr = 0; rr < 8; ++rr) {
-    const int row = wid * 8 + rr, grow = row_base + row;
+  for (int rr = 0; rr < ENR; ++rr) {
+    const int row = wid * ENR + rr, grow = row_base + row;
     dot[rr] = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -180,79 +178,94 @@ __device__ __forceinline__ void ens_ln_rows(const float* Cs, int wid, int lane, 
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1)
 #pragma unroll
-      for (int rr = 0; rr < 8; ++rr) dot[rr] += __shfl_xor(dot[rr], o);
+      for (int rr = 0; rr < ENR; ++rr) dot[rr] += __shfl_xor(dot[rr], o);
 #pragma unroll
-    for (int rr = 0; rr < 8; ++rr) {
-      const int grow = row_base + wid * 8 + rr;
+    for (int rr = 0; rr < ENR; ++rr) {
+      const int grow = row_base + wid * ENR + rr;
       if (lane == 0 && grow < B) q[grow] = dot[rr] + hb[0];
     }
   }
 }
 
-__global__ __launch_bounds__(256, 1) void ens_fwd_kernel(const EnsFwdArgs a) {
+// K slabs of both layers form ONE sequence s = 0 .. n1 + 7 (n1 = ceil(din / 32) slabs of layer 1, then the 8 of layer 2)
+// that runs through a ring of four register sets and two LDS buffers: in step s the block multiplies slab s from LDS
+// buffer s & 1, writes slab s + 1 (loaded four steps ago) into the other buffer and requests slab s + 5 -- one barrier per
+// step, and four steps (~4 us) for a load to land: the blocks are few (E x B / 32) and each walks its K loop alone on its
+// CU, so the memory round trip of a step is not hidden by anybody else.  R = n1 % 4 makes every ring index static.
+template <int R>
+__global__ __launch_bounds__(ENT, 1) void ens_fwd_kernel(const EnsFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t e_smem[];
-  uint32_t* const Xs = e_smem;                       // [hi, lo][32][E_LDKW_X]
-  uint32_t* const Hs = Xs + 2 * E_XPART;             // [hi, lo][32][E_LDKW_H]
-  uint32_t* const Ws = Hs + 2 * E_HPART;             // [hi, lo][16][E_LDW]
-  float* const Cs = reinterpret_cast<float*>(Ws + 2 * E_WPART);
+  uint32_t* const Xs = e_smem;                       // [buf][hi, lo][32][E_LDKW_X]
+  uint32_t* const Ws = Xs + 4 * E_XPART;             // [buf][hi, lo][16][E_LDW]
+  uint32_t* const Hs = Ws + 4 * E_WPART;             // [hi, lo][32][E_LDKW_H]
+  float* const Cs = reinterpret_cast<float*>(Hs + 2 * E_HPART);
   const int e = blockIdx.y, row_base = blockIdx.x * EBM;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const float* w0 = a.w0 + e * a.w0_ms;
   const float* w1 = a.w1 + e * a.w1_ms;
-  const int kp = tid >> 6, n4 = (tid & 63) * 4;      // weight slab slot: k pairs kp + 4 i, columns n4 .. n4 + 3
-  const int xr = tid >> 3, xk = (tid & 7) * 4;       // x slab slot: row xr, k xk .. xk + 3
+  const int kp = tid >> 6, n4 = (tid & 63) * 4;      // weight slab slot: k pairs kp + 8 i, columns n4 .. n4 + 3
+  const int xr = tid >> 4, xk = (tid & 15) * 2;      // x slab slot: row xr, k xk, xk + 1
+  const int n1 = (a.din + EBK - 1) / EBK;
+  const float* xrow = a.inp + (long long)min(row_base + xr, a.B - 1) * a.ld_inp;
+  const bool xrow_ok = row_base + xr < a.B;
 
-  f32x16 acc[2];
+  f32x16 acc;
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
-#pragma unroll
-    for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
+  for (int q = 0; q < 16; ++q) acc[q] = 0.f;
 
-  // ---- layer 1: K = din.  Two register sets: the loads of slab t + 2 are issued while slab t is multiplied, so a
-  // K-step costs half a memory round trip (the blocks are few and each walks its K loop alone on its CU).
-  // The whole 256 x 64-column share of layer 2's kernel (8 slabs, 256 registers of the 512 a wave has here) is requested
-  // first and lands while layer 1 runs: layer 2's K loop then has no global load in it.
-  WRegs w1r[EH / EBK];
-  WRegs wr[2];
-  float xv[2][4];
-  auto xload = [&](int k0, float (&x)[4]) {
-    const int grow = row_base + xr;
+  WRegs wr[4];
+  float xv[4][2];
+  // every load is unconditional (clamped address; zeroed when written to LDS): slabs past the end of the sequence cost a
+  // few cached loads
+  auto issue = [&](auto set_tag, int sl) {
+    constexpr int S_ = decltype(set_tag)::value;
+    const bool l1 = sl < n1;
+    const int k0 = (l1 ? sl : sl - n1) * EBK;
+    ens_wload(l1 ? w0 : w1, l1 ? a.din : EH, k0, kp, n4, wr[S_]);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int k = k0 + xk + j;
-      const float v = a.inp[(long long)min(grow, a.B - 1) * a.ld_inp + min(k, a.din - 1)];
-      x[j] = (grow < a.B && k < a.din) ? v : 0.f;
+    for (int j = 0; j < 2; ++j) xv[S_][j] = xrow[min(sl * EBK + xk + j, a.din - 1)];
+    __builtin_amdgcn_sched_barrier(0);     // keep the loads HERE: hipcc otherwise sinks them towards their use, four steps later
+  };
+  auto store = [&](auto set_tag, int buf, int sl) {      // slab sl (held by this set) -> LDS buffer buf
+    constexpr int S_ = decltype(set_tag)::value;
+    const bool l1 = sl < n1;
+    ens_wstore(Ws + buf * 2 * E_WPART, l1 ? a.din : EH, (l1 ? sl : sl - n1) * EBK, kp, n4, wr[S_]);
+    if (l1) {
+      float x[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) x[j] = xv[S_][j] * ((xrow_ok && sl * EBK + xk + j < a.din) ? 1.f : 0.f);
+      uint32_t h0, l0;
+      split_pair(x[0], x[1], h0, l0);
+      uint32_t* d = Xs + buf * 2 * E_XPART + xr * E_LDKW_X + (xk >> 1);
+      d[0] = h0;
+      d[E_XPART] = l0;
     }
   };
-  auto xstore = [&](const float (&x)[4]) {
-    uint32_t h0, l0, h1, l1;
-    split_pair(x[0], x[1], h0, l0);
-    split_pair(x[2], x[3], h1, l1);
-    uint32_t* d = Xs + xr * E_LDKW_X + (xk >> 1);
-    *reinterpret_cast<uint2*>(d) = make_uint2(h0, h1);
-    *reinterpret_cast<uint2*>(d + E_XPART) = make_uint2(l0, l1);
+  constexpr std::integral_constant<int, 0> T0{};
+  constexpr std::integral_constant<int, 1> T1{};
+  constexpr std::integral_constant<int, 2> T2{};
+  constexpr std::integral_constant<int, 3> T3{};
+  issue(T0, 0); issue(T1, 1); issue(T2, 2); issue(T3, 3);
+  store(T0, 0, 0);
+  issue(T0, 4);                                       // set 0 is free again: every later step refills the set it stores
+  __syncthreads();
+  // layer-1 step of slab sl, whose ring position U = sl % 4 is static
+  auto step1 = [&](auto u_tag, auto next_tag, int sl) {
+    constexpr int U = decltype(u_tag)::value;
+    ens_mma(Xs + (U & 1) * 2 * E_XPART, E_XPART, E_LDKW_X, 0, Ws + (U & 1) * 2 * E_WPART, wid, r, h, acc);
+    store(next_tag, (U + 1) & 1, sl + 1);
+    issue(next_tag, sl + 5);
+    __syncthreads();
   };
-  xload(0, xv[0]);
-  ens_wload(w0, a.din, 0, kp, n4, wr[0]);
-  xload(EBK, xv[1]);
-  ens_wload(w0, a.din, EBK, kp, n4, wr[1]);
-#pragma unroll
-  for (int t = 0; t < EH / EBK; ++t) ens_wload(w1, EH, t * EBK, kp, n4, w1r[t]);
-  for (int k0 = 0; k0 < a.din; k0 += 2 * EBK) {
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int kk = k0 + u * EBK;
-      if (kk >= a.din) break;                         // block-uniform
-      xstore(xv[u]);
-      ens_wstore(Ws, kp, n4, wr[u]);
-      __syncthreads();
-      xload(kk + 2 * EBK, xv[u]);                     // past din: zeros, no memory access
-      ens_wload(w0, a.din, kk + 2 * EBK, kp, n4, wr[u]);
-      ens_mma(Xs, E_XPART, E_LDKW_X, 0, Ws, wid, r, h, acc);
-      __syncthreads();
-    }
+  int sl = 0;
+  for (; sl + 4 <= n1; sl += 4) {
+    step1(T0, T1, sl); step1(T1, T2, sl + 1); step1(T2, T3, sl + 2); step1(T3, T0, sl + 3);
   }
+  if constexpr (R >= 1) step1(T0, T1, sl);
+  if constexpr (R >= 2) step1(T1, T2, sl + 1);
+  if constexpr (R >= 3) step1(T2, T3, sl + 2);
+  // ---- layer 1 done (and layer 2's first weight slab is already in LDS buffer n1 & 1)
   ens_acc_to_tile(Cs, wid, r, h, acc);
   __syncthreads();
   const long long vo = e * a.v_ms;
@@ -260,18 +273,25 @@ __global__ __launch_bounds__(256, 1) void ens_fwd_kernel(const EnsFwdArgs a) {
   ens_ln_rows(Cs, wid, lane, row_base, a.B, a.b0 + vo, a.use_ln ? a.g0 + vo : nullptr, a.use_ln ? a.be0 + vo : nullptr,
               a.use_ln, a.h0 ? a.h0 + ro * EH : nullptr, a.xh0 ? a.xh0 + ro * EH : nullptr, a.rs0 ? a.rs0 + ro : nullptr, Hs,
               nullptr, nullptr, nullptr);
-  // ---- layer 2: K = 256, A operand resident in LDS
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
-#pragma unroll
-    for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
-#pragma unroll
-  for (int t = 0; t < EH / EBK; ++t) {
-    ens_wstore(Ws, kp, n4, w1r[t]);
-    __syncthreads();                                  // (first pass: also orders the h0 image behind its writers)
-    ens_mma(Hs, E_HPART, E_LDKW_H, t * (EBK / 2), Ws, wid, r, h, acc);
+  for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+  __syncthreads();                                    // the h0 image is complete
+  // ---- layer 2: K = 256, A operand resident in LDS; ring position of its slab t is (R + t) % 4
+  auto step2 = [&](auto u_tag, auto next_tag, int t) {
+    constexpr int U = decltype(u_tag)::value;
+    ens_mma(Hs, E_HPART, E_LDKW_H, t * (EBK / 2), Ws + (U & 1) * 2 * E_WPART, wid, r, h, acc);
+    if (t + 1 < EH / EBK) store(next_tag, (U + 1) & 1, n1 + t + 1);
+    if (t + 5 < EH / EBK) issue(next_tag, n1 + t + 5);
     __syncthreads();
-  }
+  };
+  auto run2 = [&](auto a0, auto a1, auto a2, auto a3) {      // a0 = ring position of layer 2's slab 0
+    step2(a0, a1, 0); step2(a1, a2, 1); step2(a2, a3, 2); step2(a3, a0, 3);
+    step2(a0, a1, 4); step2(a1, a2, 5); step2(a2, a3, 6); step2(a3, a0, 7);
+  };
+  if constexpr (R == 0) run2(T0, T1, T2, T3);
+  if constexpr (R == 1) run2(T1, T2, T3, T0);
+  if constexpr (R == 2) run2(T2, T3, T0, T1);
+  if constexpr (R == 3) run2(T3, T0, T1, T2);
   ens_acc_to_tile(Cs, wid, r, h, acc);
   __syncthreads();
   ens_ln_rows(Cs, wid, lane, row_base, a.B, a.b1 + vo, a.use_ln ? a.g1 + vo : nullptr, a.use_ln ? a.be1 + vo : nullptr,
@@ -295,17 +315,27 @@ extern "C" int serl_ensemble_fwd_fused(const float* inp, int ld_inp, int din, in
   SERL_CHECK_ARG(serl_get_matmul_precision() == 1, "ensemble_fwd_fused: bf16_3x precision only");
   SERL_CHECK_ARG(((uintptr_t)w0 & 15) == 0 && ((uintptr_t)w1 & 15) == 0 && w0_member_stride % 4 == 0 && w1_member_stride % 4 == 0,
                  "ensemble_fwd_fused: kernels must be 16-byte aligned");
+  static_assert(E_LDS <= 160 * 1024, "LDS");
   static bool opted[64] = {};
   int dev = 0;
   SERL_CHECK_HIP(hipGetDevice(&dev), "ensemble_fwd_fused");
   if (dev >= 0 && dev < 64 && !opted[dev]) {
-    SERL_CHECK_HIP(hipFuncSetAttribute((const void*)ens_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, E_LDS),
-                   "ensemble_fwd_fused");
+    const void* ks[4] = {(const void*)ens_fwd_kernel<0>, (const void*)ens_fwd_kernel<1>, (const void*)ens_fwd_kernel<2>,
+                         (const void*)ens_fwd_kernel<3>};
+    for (const void* k : ks)
+      SERL_CHECK_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, E_LDS), "ensemble_fwd_fused");
     opted[dev] = true;
   }
   EnsFwdArgs a{inp, ld_inp, din, B, w0, b0, g0, be0, w1, b1, g1, be1, hw, hb, w0_member_stride, w1_member_stride,
                vec_member_stride, head_bias_member_stride, use_ln, h0, h1, xh0, xh1, rs0, rs1, q};
-  hipLaunchKernelGGL(ens_fwd_kernel, dim3(cdiv(B, EBM), E), dim3(256), E_LDS, (hipStream_t)stream, a);
+  const dim3 grid(cdiv(B, EBM), E);
+  hipStream_t st = (hipStream_t)stream;
+  switch (cdiv(din, EBK) % 4) {
+    case 0: hipLaunchKernelGGL(ens_fwd_kernel<0>, grid, dim3(ENT), E_LDS, st, a); break;
+    case 1: hipLaunchKernelGGL(ens_fwd_kernel<1>, grid, dim3(ENT), E_LDS, st, a); break;
+    case 2: hipLaunchKernelGGL(ens_fwd_kernel<2>, grid, dim3(ENT), E_LDS, st, a); break;
+    default: hipLaunchKernelGGL(ens_fwd_kernel<3>, grid, dim3(ENT), E_LDS, st, a); break;
+  }
   SERL_CHECK_LAUNCH("ensemble_fwd_fused");
   return SERL_OK;
 }
