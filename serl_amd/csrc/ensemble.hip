@@ -39,6 +39,9 @@ struct EnsFwdArgs {
   const float *w0, *b0, *g0, *be0, *w1, *b1, *g1, *be1, *hw, *hb;   // member 0 of the launch; member e at e * stride
   long long w0_ms, w1_ms, v_ms, hb_ms;                              // member strides (floats): kernels, 256-vectors, head bias
   int use_ln;
+  int width;                                                         // = 256 at run time: the LayerNorm statistics divide by a
+                                                                     // run-time N exactly as ln_act_fwd_kernel does (a constant
+                                                                     // lets hipcc fuse the division differently: 1-ulp differences)
   float *h0, *h1, *xh0, *xh1, *rs0, *rs1;                           // (E, B, 256) / (E, B); nullptr: not saved
   float* q;                                                          // (E, B)
 };
@@ -100,7 +103,8 @@ __device__ __forceinline__ void ens_acc_to_tile(float* Cs, int wn, int r, int h,
 // rows [4 wid, 4 wid + 4) of the fp32 tile: bias, LayerNorm, ReLU exactly as ln_act_fwd_kernel (lane handles columns
 // lane + 64 i); y to HBM (hout) and / or to the bf16 hi / lo image of the next layer (himg); head: q = y . hw + hb
 __device__ __forceinline__ void ens_ln_rows(const float* Cs, int wid, int lane, int row_base, int B, const float* bias,
-                                            const float* gamma, const float* beta, int use_ln, float* hout, float* xhout,
+                                            const float* gamma, const float* beta, int use_ln, int width, float* hout,
+                                            float* xhout,
                                             float* rsout, uint32_t* himg, const float* hw, const float* hb, float* q) {
   float bi[4], ga[4], be[4], hv[4];
 #pragma unroll
@@ -123,7 +127,7 @@ __device__ __forceinline__ void ens_ln_rows(const float* Cs, int wid, int lane, 
       float v = 0.f;
       v += Cs[row * E_LDC + lane + 64 * i];
       v += bi[i];
-      z[rr][i] = v; s1[rr] += v; s2[rr] += v * v;
+      z[rr][i] = v; s1[rr] += v; s2[rr] = fmaf(v, v, s2[rr]);
     }
   }
   float mean[ENR], mul[ENR];
@@ -140,8 +144,8 @@ __device__ __forceinline__ void ens_ln_rows(const float* Cs, int wid, int lane, 
   for (int rr = 0; rr < ENR; ++rr) {
     mean[rr] = 0.f; mul[rr] = 1.f;
     if (use_ln) {
-      mean[rr] = s1[rr] / (float)EH;
-      const float var = fmaxf(s2[rr] / (float)EH - mean[rr] * mean[rr], 0.f);
+      mean[rr] = s1[rr] / (float)width;
+      const float var = fmaxf(fmaf(-mean[rr], mean[rr], s2[rr] / (float)width), 0.f);
       mul[rr] = rsqrtf(var + ENS_LN_EPS);
       const int grow = row_base + wid * ENR + rr;
       if (rsout && lane == 0 && grow < B) rsout[grow] = mul[rr];
@@ -159,7 +163,7 @@ __device__ __forceinline__ void ens_ln_rows(const float* Cs, int wid, int lane, 
       if (use_ln) {
         const float xh = (v - mean[rr]) * mul[rr];
         if (xhout && grow < B) xhout[(long long)grow * EH + n] = xh;
-        v = (v - mean[rr]) * (mul[rr] * ga[i]) + be[i];
+        v = fmaf(v - mean[rr], mul[rr] * ga[i], be[i]);
       }
       v = fmaxf(v, 0.f);
       if (grow >= B) v = 0.f;
@@ -171,7 +175,7 @@ __device__ __forceinline__ void ens_ln_rows(const float* Cs, int wid, int lane, 
         d[0] = (unsigned short)hi;
         d[2 * E_HPART] = (unsigned short)lo;
       }
-      dot[rr] += v * hv[i];
+      dot[rr] = fmaf(v, hv[i], dot[rr]);
     }
   }
   if (hw) {
@@ -271,7 +275,7 @@ __global__ __launch_bounds__(ENT, 1) void ens_fwd_kernel(const EnsFwdArgs a) {
   const long long vo = e * a.v_ms;
   const long long ro = (long long)e * a.B;
   ens_ln_rows(Cs, wid, lane, row_base, a.B, a.b0 + vo, a.use_ln ? a.g0 + vo : nullptr, a.use_ln ? a.be0 + vo : nullptr,
-              a.use_ln, a.h0 ? a.h0 + ro * EH : nullptr, a.xh0 ? a.xh0 + ro * EH : nullptr, a.rs0 ? a.rs0 + ro : nullptr, Hs,
+              a.use_ln, a.width, a.h0 ? a.h0 + ro * EH : nullptr, a.xh0 ? a.xh0 + ro * EH : nullptr, a.rs0 ? a.rs0 + ro : nullptr, Hs,
               nullptr, nullptr, nullptr);
 #pragma unroll
   for (int q = 0; q < 16; ++q) acc[q] = 0.f;
@@ -295,7 +299,7 @@ __global__ __launch_bounds__(ENT, 1) void ens_fwd_kernel(const EnsFwdArgs a) {
   ens_acc_to_tile(Cs, wid, r, h, acc);
   __syncthreads();
   ens_ln_rows(Cs, wid, lane, row_base, a.B, a.b1 + vo, a.use_ln ? a.g1 + vo : nullptr, a.use_ln ? a.be1 + vo : nullptr,
-              a.use_ln, a.h1 ? a.h1 + ro * EH : nullptr, a.xh1 ? a.xh1 + ro * EH : nullptr, a.rs1 ? a.rs1 + ro : nullptr,
+              a.use_ln, a.width, a.h1 ? a.h1 + ro * EH : nullptr, a.xh1 ? a.xh1 + ro * EH : nullptr, a.rs1 ? a.rs1 + ro : nullptr,
               nullptr, a.hw + vo, a.hb + e * a.hb_ms, a.q + ro);
 }
 
@@ -327,7 +331,7 @@ extern "C" int serl_ensemble_fwd_fused(const float* inp, int ld_inp, int din, in
     opted[dev] = true;
   }
   EnsFwdArgs a{inp, ld_inp, din, B, w0, b0, g0, be0, w1, b1, g1, be1, hw, hb, w0_member_stride, w1_member_stride,
-               vec_member_stride, head_bias_member_stride, use_ln, h0, h1, xh0, xh1, rs0, rs1, q};
+               vec_member_stride, head_bias_member_stride, use_ln, EH, h0, h1, xh0, xh1, rs0, rs1, q};
   const dim3 grid(cdiv(B, EBM), E);
   hipStream_t st = (hipStream_t)stream;
   switch (cdiv(din, EBK) % 4) {

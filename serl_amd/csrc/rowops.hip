@@ -46,14 +46,14 @@ __global__ __launch_bounds__(256) void ln_act_fwd_kernel(const LnFwdArgs a) {
     }
     z[i] = v;
     s1 += v;
-    s2 += v * v;
+    s2 = fmaf(v, v, s2);          // explicit FMAs: ensemble.hip repeats this arithmetic and must round identically
   }
   float mean = 0.f, mul = 1.f;
   if (a.use_ln) {
     s1 = wave_sum(s1);
     s2 = wave_sum(s2);
     mean = s1 / (float)a.N;
-    const float var = fmaxf(s2 / (float)a.N - mean * mean, 0.f);
+    const float var = fmaxf(fmaf(-mean, mean, s2 / (float)a.N), 0.f);
     mul = rsqrtf(var + LN_EPS);
     if (a.rstd && lane == 0) a.rstd[row] = mul;
   }
@@ -69,13 +69,13 @@ __global__ __launch_bounds__(256) void ln_act_fwd_kernel(const LnFwdArgs a) {
       if (a.use_ln) {
         const float xh = (v - mean) * mul;
         if (a.xhat) a.xhat[(long long)row * a.N + n] = xh;
-        v = (v - mean) * (mul * gamma[n]) + beta[n];
+        v = fmaf(v - mean, mul * gamma[n], beta[n]);
       }
       if (a.act == ACT_RELU) v = fmaxf(v, 0.f);
       else if (a.act == ACT_TANH) v = tanhf(v);
       else if (a.act == ACT_LEAKY) v = v > 0.f ? v : 0.01f * v;
       a.y[(long long)row * a.ldy + n] = v;
-      if (hw) dot += v * hw[n];                 // same lane/column order as rowdot_kernel: bit-identical sums
+      if (hw) dot = fmaf(v, hw[n], dot);                 // same lane/column order as rowdot_kernel: bit-identical sums
     }
   }
   if (hw) {
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const float* h, const float
   if (row >= R) return;
   const int e = row / rows_per_group;
   float s = 0.f;
-  for (int n = lane; n < N; n += 64) s += h[(long long)row * N + n] * w[e * w_gs + n];
+  for (int n = lane; n < N; n += 64) s = fmaf(h[(long long)row * N + n], w[e * w_gs + n], s);
   s = wave_sum(s);
   if (lane == 0) q[row] = s + b[e * b_gs];
 }

@@ -656,3 +656,41 @@ def test_drq_mobilenet_encoder_matches_oracle(dev, utd, prec):
     oa, osync2 = ol.sample_actions(osync, ocfg, ob)
     assert np.allclose(a, oa, atol=5e-4) and np.array_equal(agent2.rng, osync2["rng"])
     assert np.allclose(agent.eval_actions(ob), ol.eval_actions(osync, ocfg, ob), atol=5e-4)
+
+
+@pytest.mark.parametrize("kind", ["state_ln", "state_plain", "pixel"])
+def test_fused_ensemble_forward_bit_identical(dev, kind, monkeypatch):
+    """csrc/ensemble.hip (the critic ensemble's forward in one launch) keeps the products, the k order and the LayerNorm /
+    head reductions of the four launches it replaces: two agents created from the same seed, one with the fused kernel and
+    one with SERL_AMD_ENS_FUSED=0, must hold identical bits after two update() calls (REDQ subsample with a negative member
+    stride included), at a batch that is not a multiple of the kernel's 32-row blocks."""
+    from serl_amd.agents import DrQLearner, SACLearner
+    import serl_amd
+    assert serl_amd.get_matmul_precision() == "bf16_3x"
+    rng = np.random.default_rng(3)
+    if kind == "pixel":
+        keys = ("wrist_1", "wrist_2")
+        obs_space, act_space = pixel_spaces(keys, 32, 32, 1, 19, 7)
+        mk = lambda: DrQLearner.create(5, obs_space, act_space, pixel_keys=keys, num_qs=10, num_min_qs=2,
+                                       critic_layer_norm=True, backup_entropy=False)
+        batches = [make_pixel_batch(rng, 2 * 20, keys, 32, 32, 1, 19, 7, packed=True) for _ in range(2)]
+        upd = lambda a, b: a.update(b, 2, pixel_keys=keys)
+    else:
+        obs_space, act_space = state_spaces(17, 6)
+        ln = kind == "state_ln"
+        mk = lambda: SACLearner.create(5, obs_space, act_space, num_qs=10 if ln else 2, num_min_qs=2 if ln else None,
+                                       critic_layer_norm=ln)
+        batches = [make_state_batch(rng, 3 * 50, 17, 6) for _ in range(2)]
+        upd = lambda a, b: a.update(b, 3)
+    out = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("SERL_AMD_ENS_FUSED", fused)        # read when the native handle is created
+        agent = mk()
+        infos = []
+        for b in batches:
+            agent, info = upd(agent, b)
+            infos.append(dict(info))
+        out[fused] = (agent, infos)
+    for name in ("actor", "critic", "target_critic"):
+        assert torch.equal(getattr(out["1"][0], name).store.flat, getattr(out["0"][0], name).store.flat), name
+    assert out["1"][1] == out["0"][1]
