@@ -192,8 +192,10 @@ int colsum(const float* x0, float* out0, int ng, int rpg, int N, int ldx, long l
 
 int ksplit(int K) {   // split-K factor for the skinny (M = batch) GEMMs so that >= ~256 blocks are in flight
   if (K < 1024) return 1;
-  int n = 8;
-  while (n > 1 && (K + n - 1) / n < 256) n /= 2;
+  static const int nmax = getenv("SERL_AMD_KSPLIT_MAX") ? atoi(getenv("SERL_AMD_KSPLIT_MAX")) : 8;      // A/B switch
+  static const int kmin = getenv("SERL_AMD_KSPLIT_MIN_K") ? atoi(getenv("SERL_AMD_KSPLIT_MIN_K")) : 256;
+  int n = nmax;
+  while (n > 1 && (K + n - 1) / n < kmin) n /= 2;
   const int klen = ((K + n - 1) / n + 15) / 16 * 16;
   return (K + klen - 1) / klen;
 }
