@@ -70,7 +70,7 @@ int serl_convs_fwd(int ngroups, const void* const* x, const void* const* wf, con
  * LDS, all taps read from there; C = 64 -> F = 128 by four waves that hold the whole weight matrix in registers;
  * bit-identical output).  enable = 0 keeps every layer on the im2col kernels -- for A/B measurements and the bit-identity
  * test of the paths; 2 = without the 4-wave kernel; 3 = plus the LDS-DMA ring GEMM (csrc/sgemm_ring.h) for the deep
- * layers.  Process-wide; no counterpart in the reference (XLA picks its convolution algorithm itself,
+ * layers; 4 = serl_convs_fwd12 on its one-set kernel (default: two wave sets half a period apart).  Process-wide; no counterpart in the reference (XLA picks its convolution algorithm itself,
  * two_d4pg_encoder.py:30-38). */
 int serl_convs_set_patch_kernels(int enable);
 /* Layers 1 + 2 of a NO-GRADIENT encoder pass (target critic, actor: two_d4pg_encoder.py:30-38 under stop_gradient /

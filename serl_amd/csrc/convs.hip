@@ -582,11 +582,13 @@ extern "C" int serl_convs_prep_weights_multi(int njobs, const float* const* w, v
 // patch kernels only, 3 = as 1 plus the LDS-DMA ring GEMM (sgemm_ring.h, also bit-identical) for the deep layers no patch
 // kernel takes.  The ring GEMM is 5-8 % faster than the register-staged kernel stand-alone but takes the CU's whole LDS
 // (one block per CU), so nothing of the other streams runs next to it: -1 % on the whole update, hence not the default.
-static int g_patch_kernels = 1, g_ring_kernels = 0, g_wide_kernels = 1;
+// 4 = as 1 with the one-set fused layers-1+2 kernel (pconv_fused12_kernel) instead of the two-set one.
+static int g_patch_kernels = 1, g_ring_kernels = 0, g_wide_kernels = 1, g_f12_two_sets = 1;
 extern "C" int serl_convs_set_patch_kernels(int enable) {
   g_patch_kernels = enable ? 1 : 0;
   g_ring_kernels = enable == 3 ? 1 : 0;
-  g_wide_kernels = enable == 1 || enable == 3 ? 1 : 0;
+  g_wide_kernels = enable == 1 || enable == 3 || enable == 4 ? 1 : 0;
+  g_f12_two_sets = enable == 4 ? 0 : 1;
   return SERL_OK;
 }
 
@@ -679,7 +681,7 @@ extern "C" int serl_convs_fwd12(int ngroups, const void* const* x_u8, const void
   const int IH = (IH1 - 3) / 2 + 1;
   a.IW = (IW1 - 3) / 2 + 1;
   a.OH = (IH - 3) / 2 + 1; a.OW = (a.IW - 3) / 2 + 1;
-  a.nbands = cdiv(a.OH, PFusedCfg::R);
+  a.nbands = cdiv(a.OH, g_f12_two_sets ? PFusedPPCfg::R : PFusedCfg::R);
   a.d_bands = make_fastdiv(a.nbands);
   for (int i = 0; i < ngroups; ++i) {
     SERL_CHECK_ARG(bias1[i] && bias2[i], "convs_fwd12: null bias");
@@ -687,6 +689,7 @@ extern "C" int serl_convs_fwd12(int ngroups, const void* const* x_u8, const void
     a.wf2[i] = (const ushort_t*)wf2[i]; a.bias2[i] = bias2[i]; a.y[i] = (ushort_t*)y[i];
     a.rmask[i] = rmask ? (unsigned char*)rmask[i] : nullptr;
   }
+  if (g_f12_two_sets) return pconv_fused12pp_launch(a, ngroups, (hipStream_t)stream, "convs_fwd12(two sets)");
   return pconv_fused12_launch(a, ngroups, (hipStream_t)stream, "convs_fwd12");
 }
 
@@ -835,3 +838,9 @@ extern "C" int serl_convs_wgrad_noalloc(int ngroups, const void* const* x, const
   return convs_wgrad_impl("convs_wgrad_noalloc", ngroups, x, dz, dw, dbias, ptr, SERL_WGRAD_SCRATCH_BYTES, in_u8, B, IH,
                           IW, C, KH, KW, stride, F, stream);
 }
+
+#ifdef PFPP_TRACE
+extern "C" int serl_debug_pf_trace(unsigned int* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(pf_trace), sizeof(unsigned int) * 256) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -1100,6 +1100,402 @@ static int pconv_fused12_launch(const PConvFusedArgs& a, int ngroups, hipStream_
   return SERL_OK;
 }
 
+// LDS reads of the two-set kernel, by hand: with an LDS-DMA in flight hipcc's wait-count pass treats lgkmcnt as unordered
+// (it models global_load_lds as a flat access) and turns every wait for an LDS read into lgkmcnt(0), i.e. it also waits
+// for the prefetches issued since.  These are issued and NOT waited for; the counted s_waitcnt that follows names the
+// registers as read-write operands, so no use can move above it.  Offsets are immediates.
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+#define PF_LD_D(d01, d2, addr, imm)                                                                                     \
+  asm volatile("ds_read2_b32 %0, %2 offset0:%3 offset1:%4\n\tds_read_b32 %1, %2 offset:%5"                               \
+               : "=&v"(d01), "=&v"(d2) : "v"(addr), "n"((imm) / 4), "n"((imm) / 4 + 1), "n"((imm) + 8) : "memory")
+#define PF_LD_2X128(o0, o1, a0, a1, imm0, imm1)                                                                         \
+  asm volatile("ds_read_b128 %0, %2 offset:%4\n\tds_read_b128 %1, %3 offset:%5"                                          \
+               : "=&v"(o0), "=&v"(o1) : "v"(a0), "v"(a1), "n"(imm0), "n"(imm1) : "memory")
+
+// ------------------------------------------------------------------------------------------------ conv1 + conv2, two wave sets
+// pconv_fused12_kernel runs its phases one after the other on all 8 waves: the layer-1 phase is VALU work (uint8 ->
+// bf16 conversion, S-format rounding, 2-byte LDS writes: ~240 VALU instructions per 12 MFMAs), the layer-2 phase is
+// MFMAs only, the output phase VALU + stores again -- the matrix cores idle through two thirds of an item (0.27 of
+// their roof).  Here the block is split into two sets of four waves (one wave of each set per SIMD) that work half a
+// period apart on items of R = 2 output rows: while set s converts and multiplies layer 1 of item i + 1 into its own
+// patch, set s^1 runs the layer-2 K loop and the output path of item i from its patch, so a SIMD always has one
+// VALU-bound and one MFMA-bound wave to pick from.  One block barrier per slot; a set's patch, uint8 buffer and the
+// output staging tile of a wave are private to it, the only cross-set access is the copy of the shared halo row (last
+// layer-1 row of item i = first of item i + 1), read from the other set's patch while that set only reads it.
+// Same operands, k order and MFMA sequence per output as the one-set kernel: bit-identical.
+struct PFusedPPCfg {
+  static constexpr int C = 32, F = 64, R = 2, OWP = 32, NT = 512;
+  static constexpr int REC = 4 * C, PARB = OWP * REC, ROWB = 2 * PARB, NR = 2 * R + 1, PATCH = NR * ROWB;
+  static constexpr int KP = 9 * C, WROW = KP * 2 + 16, WIMG = 2 * F * WROW;
+  static constexpr int U8ROWS = 4 * R + 3;               // uint8 rows per item
+  static constexpr int RB1MAX = 1152;
+  static constexpr int U8BUF = 13 * 1024;                // 3 DMA pieces per lane of a set + one shared piece
+  static constexpr int W1IMG = 6 * 2 * 32 * 32;
+  static constexpr int LDT = 36, STG = 32 * LDT * 4;     // fp32 output tile of one wave
+  static constexpr int LDS = 2 * PATCH + 2 * U8BUF + W1IMG + 8 * STG;
+  static_assert(U8ROWS * RB1MAX + 64 <= U8BUF && WIMG <= 2 * PATCH && LDS <= 160 * 1024, "LDS");
+  static_assert(RB1MAX == PFusedCfg::RB1MAX && R * 2 == PFusedCfg::R, "band geometry shared with pconv_fused12_kernel");
+};
+
+#ifdef PFPP_TRACE       // phase timestamps of block 0 (slots 8..11), tools/pf_trace.py
+__device__ uint32_t pf_trace[256];
+#define PF_TP(i) { if (k >= 8 && k < 12 && lane == 0) reinterpret_cast<uint32_t*>(p_smem + PFusedPPCfg::LDS)[((k - 8) * 8 + wid) * 8 + (i)] = (uint32_t)clock64(); }
+#else
+#define PF_TP(i)
+#endif
+#ifdef PFPP_TRACE
+#define PFPP_TRACE_LDS 1024
+#else
+#define PFPP_TRACE_LDS 0
+#endif
+__global__ __launch_bounds__(512, 1) void pconv_fused12pp_kernel(const PConvFusedArgs a) {
+  typedef PFusedPPCfg G;
+  constexpr int C = G::C, F = G::F, R = G::R, NT = G::NT;
+  constexpr int REC = G::REC, ROWB = G::ROWB, PARB = G::PARB;
+  constexpr int KS = C / 16, NS = 9 * KS;
+  constexpr int Kp = G::KP, WROW = G::WROW, LDT = G::LDT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char p_smem[];
+  unsigned char* const patches = p_smem;                     // [2][PATCH]: layer-1 output, one per wave set
+  unsigned char* const u8bufs = p_smem + 2 * G::PATCH;       // [2][U8BUF]
+  unsigned char* const W1s = u8bufs + 2 * G::U8BUF;
+
+  const int z = blockIdx.z;
+  const int nitems = a.B * a.nbands;
+  const int per = (nitems + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int it0 = blockIdx.x * per, it1 = min(nitems, it0 + per);
+  if (it0 >= it1) return;
+  const int n_it = it1 - it0;
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+#ifdef PF12_SET_LOW
+  const int set = wid & 1, w4 = wid >> 1;
+#else
+  const int set = wid >> 2, w4 = wid & 3;                    // waves w and w + 4 share a SIMD
+#endif
+  const int wm = w4 >> 1, wn = w4 & 1;
+  const int RB1 = a.IW1 * a.C1;
+
+  // ---- layer-2 weights -> fragments in registers, layer-1 weights -> fragment image in LDS (as pconv_fused12_kernel)
+  bf16x8_t rbh[NS], rbl[NS];
+  {
+    constexpr int CPR = Kp / 8;
+    constexpr int NWC = 2 * F * CPR, NWL = (NWC + NT - 1) / NT;
+    const char* wsrc = reinterpret_cast<const char*>(a.wf2[z]);
+    u32x4_t wv[NWL];
+#pragma unroll
+    for (int i = 0; i < NWL; ++i) {
+      const int q = tid + i * NT;
+      wv[i] = *reinterpret_cast<const u32x4_t*>(q < NWC ? wsrc + (size_t)q * 16 : reinterpret_cast<const char*>(g_zero_page));
+    }
+#pragma unroll
+    for (int i = 0; i < NWL; ++i) {
+      const int q = tid + i * NT;
+      if (q < NWC) {
+        const int row = q / CPR, kc = q - row * CPR;
+        *reinterpret_cast<u32x4_t*>(p_smem + ((row & 1) * F + (row >> 1)) * WROW + kc * 16) = wv[i];
+      }
+    }
+    __syncthreads();
+    const unsigned char* wrow = p_smem + (wn * 32 + r) * WROW + h * 16;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      rbh[s] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(wrow + s * 32));
+      rbl[s] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(wrow + F * WROW + s * 32));
+    }
+  }
+  for (int id = tid; id < 6 * 2 * 32 * 2; id += NT) {
+    const int hh = id & 1, f = (id >> 1) & 31, plane = (id >> 6) & 1, s6 = id >> 7;
+    *reinterpret_cast<u32x4_t*>(W1s + ((s6 * 2 + plane) * 32 + f) * 32 + ((hh ^ ((f >> 3) & 1)) << 4)) =
+        *reinterpret_cast<const u32x4_t*>(a.wf1[z] + (size_t)(f * 2 + plane) * 96 + s6 * 16 + hh * 8);
+  }
+  const unsigned char* const w1p = W1s + r * 32 + ((h ^ ((r >> 3) & 1)) << 4);
+  const float b1 = a.bias1[z][r];
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();            // weight image consumed: the LDS is free for the patches
+
+  unsigned char* const patch = patches + set * G::PATCH;                   // this set's patch
+  const unsigned char* const opatch = patches + (set ^ 1) * G::PATCH;      // the other set's (halo row copy only)
+  unsigned char* const ubuf = u8bufs + set * G::U8BUF;
+  float* const Cs = reinterpret_cast<float*>(W1s + G::W1IMG + wid * G::STG);
+  const uint32_t cs_base = (uint32_t)(size_t)(pconv_lptr_t)Cs;
+  const uint32_t patch_l = (uint32_t)(size_t)(pconv_lptr_t)patch, ub_l = (uint32_t)(size_t)(pconv_lptr_t)ubuf;
+  const uint32_t w1_l = (uint32_t)(size_t)(pconv_lptr_t)w1p;
+  const int rec0 = r * REC, rec1 = (r + 1) * REC;
+  const int sw0 = pconv_swz<REC>(r) << 4, sw1 = pconv_swz<REC>(r + 1) << 4;
+  const int n8 = wn * 32 + (lane & 3) * 8;
+  float bs[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) bs[j] = a.bias2[z][n8 + j];
+  unsigned short* const out = a.y[z];
+  unsigned char* const mk = a.rmask[z];
+
+  // uint8 rows 4*oy0 .. 4*oy0 + 4*rows + 2 of image b -> this set's buffer: 3 pieces per lane + a 13th KB that all four
+  // waves copy (the same bytes to the same place)
+  auto dma_u8 = [&](int item) {
+    const int b = (int)fd_div((uint32_t)item, a.d_bands), band = item - b * a.nbands;
+    const int oy0 = band * R;
+    const int nbytes = (4 * min(R, a.OH - oy0) + 3) * RB1;
+    const char* src = reinterpret_cast<const char*>(a.u8[z]) + ((size_t)(b * a.IH1 + 4 * oy0)) * RB1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int pc = i < 3 ? i * 4 + w4 : 12;
+      const int off = (pc * 64 + lane) * 16;
+#ifdef PFPP_ZERO_SRC
+      const char* g = reinterpret_cast<const char*>(g_zero_page) + (off < nbytes ? (off & 4080) : 0);
+#else
+      const char* g = off < nbytes ? src + off : reinterpret_cast<const char*>(g_zero_page);
+#endif
+      __builtin_amdgcn_global_load_lds((pconv_gptr_t)g, (pconv_lptr_t)(ubuf + pc * 1024), 16, 0, 0);
+    }
+  };
+
+  dma_u8(min(it0 + set, it1 - 1));         // set s owns items it0 + s, it0 + s + 2, ...
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  // slot k: the set with (k & 1) == set computes layer 1 of item it0 + k, the other one layer 2 of item it0 + k - 1
+  for (int k = 0; k <= n_it; ++k) {
+    PF_TP(0)
+    if ((k & 1) == set) {
+      if (k < n_it) {
+        const int item = it0 + k;
+        const int b = (int)fd_div((uint32_t)item, a.d_bands), band = item - b * a.nbands;
+        const int nrows1 = 2 * min(R, a.OH - band * R) + 1;     // layer-1 output rows of this item
+        // the first layer-1 row is the last one of the previous item of this block (other set's patch, written one
+        // slot ago, only read by its owner now): copied, 8 tiles = two rounds of the four waves instead of 10 = three
+        const bool reuse = k > 0 && band > 0;
+        if (reuse) {
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk) {
+            const int off = (w4 * 2 + kk) * 1024 + lane * 16;
+            *reinterpret_cast<u32x4_t*>(patch + off) = *reinterpret_cast<const u32x4_t*>(opatch + 2 * R * ROWB + off);
+          }
+        }
+        // Four tiles of 32 pixels per row pair, two (or three) per wave.  One wave per SIMD works here, so nobody else
+        // hides the LDS latency: the uint8 dwords run two k16 steps ahead and the weight fragments one step ahead of the
+        // MFMAs (register rings; hipcc's own order was read -> wait -> convert -> read -> wait -> two dependent MFMAs,
+        // 3500 cycles per tile), across the tile boundary too.
+        PF_TP(1)
+        int t = (reuse ? 2 : 0) + w4;
+        const int tend = 2 * nrows1;
+#ifdef PFPP_NO_L1      // ablation builds
+        if (k > 1) t = tend;
+#endif
+        if (t < tend) {
+          // 8 consecutive bytes (kx, c) of input row 2 y1 + ky at pixel 2 ox1: 2-byte aligned, so three aligned dwords
+          auto tile_base = [&](int tt) { return (uint32_t)((tt >> 1) * 2 * RB1 + 2 * ((tt & 1) * 32 + r) * a.C1 + 8 * h); };
+          u32x2_t D01[3];
+          uint32_t D2[3];
+          u32x4_t Wh[2], Wl[2];
+          uint32_t base = tile_base(t);
+          uint32_t ab = ub_l + (base & ~3u);
+          // software pipeline: the uint8 dwords of step s + 3 and the weight fragments of step s + 1 are requested in
+          // step s, and the A fragment of step s + 1 is converted BETWEEN the two (dependent) MFMAs of step s, whose
+          // 32-cycle shadows would otherwise be stalls of this wave
+          PF_LD_D(D01[0], D2[0], ab, 0);
+          PF_LD_D(D01[1], D2[1], ab, 16);
+          PF_LD_D(D01[2], D2[2], ab + RB1, 0);
+          PF_LD_2X128(Wh[0], Wl[0], w1_l, w1_l, 0, 1024);
+          asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(D01[0]), "+v"(D2[0]) : : "memory");
+          u32x4_t acur;
+          {
+            const uint32_t lo4 = __builtin_amdgcn_alignbyte(D01[0][1], D01[0][0], base & 2u);
+            const uint32_t hi4 = __builtin_amdgcn_alignbyte(D2[0], D01[0][1], base & 2u);
+            const uint2 e0 = u8x4_to_bf16(lo4), e1 = u8x4_to_bf16(hi4);
+            acur = u32x4_t{e0.x, e0.y, e1.x, e1.y};
+          }
+          for (; t < tend; t += 4) {
+            const uint32_t sh = base & 2u;                       // (rows are multiples of 16 bytes: the same for all steps)
+            const uint32_t nbase = tile_base(t + 4 < tend ? t + 4 : t);
+            const uint32_t nsh = nbase & 2u;
+            const uint32_t nab = ub_l + (nbase & ~3u);           // the next tile's first steps (the last tile: its own again)
+            const uint32_t ab1 = ab + RB1, ab2 = ab1 + RB1, nab1 = nab + RB1;
+            f32x16 acc1;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc1[q] = 0.f;
+#define PF_L1_STEP(s, ADDR, IMM, SH)                                                                                    \
+            {                                                                                                           \
+              PF_LD_D(D01[(s) % 3], D2[(s) % 3], ADDR, IMM);                                                            \
+              PF_LD_2X128(Wh[((s) + 1) & 1], Wl[((s) + 1) & 1], w1_l, w1_l, (((s) + 1) % 6) * 2048, (((s) + 1) % 6) * 2048 + 1024); \
+              asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(D01[((s) + 1) % 3]), "+v"(D2[((s) + 1) % 3]), "+v"(Wh[(s) & 1]), "+v"(Wl[(s) & 1]) : : "memory"); \
+              const bf16x8_t ah = __builtin_bit_cast(bf16x8_t, acur);                                                   \
+              acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8_t, Wl[(s) & 1]), acc1, 0, 0, 0); \
+              __builtin_amdgcn_sched_barrier(0);                                                                        \
+              const uint32_t lo4 = __builtin_amdgcn_alignbyte(D01[((s) + 1) % 3][1], D01[((s) + 1) % 3][0], SH);        \
+              const uint32_t hi4 = __builtin_amdgcn_alignbyte(D2[((s) + 1) % 3], D01[((s) + 1) % 3][1], SH);            \
+              const uint2 e0 = u8x4_to_bf16(lo4);                                                                       \
+              __builtin_amdgcn_sched_barrier(0);                                                                        \
+              acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8_t, Wh[(s) & 1]), acc1, 0, 0, 0); \
+              __builtin_amdgcn_sched_barrier(0);                                                                        \
+              const uint2 e1 = u8x4_to_bf16(hi4);                                                                       \
+              acur = u32x4_t{e0.x, e0.y, e1.x, e1.y};                                                                   \
+              __builtin_amdgcn_sched_barrier(0);                                                                        \
+            }
+            PF_L1_STEP(0, ab1, 16, sh) PF_L1_STEP(1, ab2, 0, sh) PF_L1_STEP(2, ab2, 16, sh)
+            PF_L1_STEP(3, nab, 0, sh) PF_L1_STEP(4, nab, 16, sh) PF_L1_STEP(5, nab1, 0, nsh)
+#undef PF_L1_STEP
+#ifdef PFPP_TRACE
+            if (t < 6) PF_TP(3)
+#endif
+            // bias + ReLU + S-format rounding, 2 bytes per (pixel, channel, plane) into the swizzled patch (layout and
+            // swizzle arithmetic: pconv_fused12_kernel).  (Weights as the A operand would leave a lane with four
+            // consecutive channels of one pixel, i.e. 8 ds_write_b64 instead of 32 ds_write_b16 per tile, and is still
+            // bit-identical -- but needs the 16 biases of those channels in registers, which spills; measured no faster.)
+            const int y1 = t >> 1;
+            unsigned char* const tile = patch + y1 * 2 * PARB + ((t & 1) * 16 + 2 * h) * REC + (r & 7) * 2;
+            const int ch0 = ((r >> 3) ^ h) << 4;
+#pragma unroll
+            for (int q = 0; q < 16; q += 2) {
+              const float v0 = fmaxf(fmaf(acc1[q], 1.0f / 255.0f, b1), 0.f), v1 = fmaxf(fmaf(acc1[q + 1], 1.0f / 255.0f, b1), 0.f);
+              uint32_t hh, ll;
+              split_pair(v0, v1, hh, ll);
+              unsigned char* rec = tile + (((q & 3) >> 1) + 4 * (q >> 2)) * REC;
+              const int co = ch0 ^ ((2 * (q >> 2)) << 4);
+              *reinterpret_cast<unsigned short*>(rec + co) = (unsigned short)hh;
+              *reinterpret_cast<unsigned short*>(rec + (co ^ 64)) = (unsigned short)ll;
+              *reinterpret_cast<unsigned short*>(rec + PARB + co) = (unsigned short)(hh >> 16);
+              *reinterpret_cast<unsigned short*>(rec + PARB + (co ^ 64)) = (unsigned short)(ll >> 16);
+            }
+#ifdef PFPP_TRACE
+            if (t < 6) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); PF_TP(4) }
+#endif
+            base = nbase; ab = nab;
+          }
+          // the reads issued for a tile that does not come must land before their registers are anyone else's
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(D01[0]), "+v"(D2[0]), "+v"(D01[1]), "+v"(D2[1]), "+v"(D01[2]), "+v"(D2[2]),
+                       "+v"(Wh[0]), "+v"(Wl[0]), "+v"(Wh[1]), "+v"(Wl[1]) : : "memory");
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      PF_TP(2)
+    } else if (k >= 1) {
+      const int item = it0 + k - 1;
+      const int b = (int)fd_div((uint32_t)item, a.d_bands), band = item - b * a.nbands;
+      const int oy0 = band * R;
+      const int oyl = min(wm, min(R, a.OH - oy0) - 1);       // a band of one row: both row waves compute and store it
+      // this set's next item; past the end a copy nobody reads (branch-free issue, same store count for the wait)
+      dma_u8(min(it0 + k + 1, it1 - 1));
+      PF_TP(1)
+      const int arow = 2 * oyl * ROWB;
+      f32x16 acc;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+      // A fragments two k16 steps ahead of the MFMAs (ring of three register pairs, read by hand as above)
+      {
+        u32x4_t Ah[3], Al[3];
+        uint32_t pa[2][KS][2];               // [kx == 2][kc][plane]: lane address of the fragment, tap offsets are immediates
+#pragma unroll
+        for (int x2 = 0; x2 < 2; ++x2)
+#pragma unroll
+          for (int kc = 0; kc < KS; ++kc)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+              pa[x2][kc][pl] = patch_l + (uint32_t)(arow + (x2 ? rec1 : rec0) + (((kc * 2 + h + pl * (C / 8)) << 4) ^ (x2 ? sw1 : sw0)));
+#define PF_LD_A(slot, s)                                                                                                \
+        PF_LD_2X128(Ah[slot], Al[slot], pa[((s) / KS) % 3 == 2][(s) % KS][0], pa[((s) / KS) % 3 == 2][(s) % KS][1],     \
+                    ((s) / KS / 3) * ROWB + ((((s) / KS) % 3) & 1) * PARB, ((s) / KS / 3) * ROWB + ((((s) / KS) % 3) & 1) * PARB)
+#define PF_L2_STEP(s, CNT)                                                                                              \
+        {                                                                                                               \
+          if ((s) + 2 < NS) PF_LD_A(((s) + 2) % 3, ((s) + 2) % NS);                                                     \
+          asm volatile("s_waitcnt lgkmcnt(" #CNT ")" : "+v"(Ah[(s) % 3]), "+v"(Al[(s) % 3]) : : "memory");              \
+          const bf16x8_t ah = __builtin_bit_cast(bf16x8_t, Ah[(s) % 3]), al = __builtin_bit_cast(bf16x8_t, Al[(s) % 3]); \
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, rbh[s], acc, 0, 0, 0);                                      \
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, rbl[s], acc, 0, 0, 0);                                      \
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, rbh[s], acc, 0, 0, 0);                                      \
+          __builtin_amdgcn_sched_barrier(0);                                                                            \
+        }
+        static_assert(NS == 18 && KS == 2, "unrolled by hand");
+#ifdef PFPP_NO_L2
+        if (k <= 2)
+#endif
+        {
+        PF_LD_A(0, 0); PF_LD_A(1, 1);
+        PF_L2_STEP(0, 4) PF_L2_STEP(1, 4) PF_L2_STEP(2, 4) PF_L2_STEP(3, 4) PF_L2_STEP(4, 4) PF_L2_STEP(5, 4)
+        PF_L2_STEP(6, 4) PF_L2_STEP(7, 4) PF_L2_STEP(8, 4) PF_L2_STEP(9, 4) PF_L2_STEP(10, 4) PF_L2_STEP(11, 4)
+        PF_L2_STEP(12, 4) PF_L2_STEP(13, 4) PF_L2_STEP(14, 4) PF_L2_STEP(15, 4) PF_L2_STEP(16, 2) PF_L2_STEP(17, 0)
+        }
+#undef PF_L2_STEP
+#undef PF_LD_A
+      }
+      PF_TP(2)
+      // ---- output through the wave's own fp32 tile (32 pixels x 32 channels): 8 channels of one pixel per lane
+#pragma unroll
+      for (int q = 0; q < 16; ++q) Cs[((q & 3) + 8 * (q >> 2) + 4 * h) * LDT + r] = acc[q];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+        const int oxx = min((lane >> 2) + 16 * pass, a.OW - 1);
+        const size_t pix = (size_t)(b * a.OH + oy0 + oyl) * a.OW + oxx;
+        u32x4_t c0, c1;
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(c0), "=&v"(c1) : "v"(cs_base + (uint32_t)(oxx * LDT + (lane & 3) * 8) * 4u) : "memory");
+        float v[8] = {__uint_as_float(c0[0]), __uint_as_float(c0[1]), __uint_as_float(c0[2]), __uint_as_float(c0[3]),
+                      __uint_as_float(c1[0]), __uint_as_float(c1[1]), __uint_as_float(c1[2]), __uint_as_float(c1[3])};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          v[j] = fmaf(v[j], 1.0f, bs[j]);
+          if (a.relu) v[j] = fmaxf(v[j], 0.f);
+        }
+        u32x4_t hi, lo;
+        uint32_t hh, ll;
+        split_pair(v[0], v[1], hh, ll); hi[0] = hh; lo[0] = ll;
+        split_pair(v[2], v[3], hh, ll); hi[1] = hh; lo[1] = ll;
+        split_pair(v[4], v[5], hh, ll); hi[2] = hh; lo[2] = ll;
+        split_pair(v[6], v[7], hh, ll); hi[3] = hh; lo[3] = ll;
+#ifdef PFPP_NO_STORE
+        unsigned short* dst = out + (k > 2 ? 0 : pix * 2 * F) + n8 + (size_t)blockIdx.x * 4096;
+#else
+        unsigned short* dst = out + pix * 2 * F + n8;
+#endif
+        *reinterpret_cast<u32x4_t*>(dst) = hi;
+        *reinterpret_cast<u32x4_t*>(dst + F) = lo;
+        if (mk != nullptr) {
+          uint32_t bits = 0;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            bits |= (hi[j] & 0x7fffu) ? (1u << (2 * j)) : 0u;
+            bits |= (hi[j] & 0x7fff0000u) ? (2u << (2 * j)) : 0u;
+          }
+          mk[pix * (F >> 3) + (n8 >> 3)] = (unsigned char)bits;
+        }
+      }
+      PF_TP(3)
+      // the next item's uint8 rows have landed (the DMA is older than this slot's 4 or 6 stores)
+      if (mk != nullptr) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+      PF_TP(4)
+    }
+    __builtin_amdgcn_s_barrier();
+    PF_TP(5)
+  }
+#ifdef PFPP_TRACE
+  if (blockIdx.x == 0 && z == 0) {
+    __syncthreads();
+    if (tid < 256) pf_trace[tid] = reinterpret_cast<uint32_t*>(p_smem + PFusedPPCfg::LDS)[tid];
+  }
+#endif
+}
+
+static int pconv_fused12pp_launch(const PConvFusedArgs& a, int ngroups, hipStream_t st, const char* name) {
+  static bool opted[64] = {};
+  static int ncu[64] = {};
+  int dev = 0;
+  SERL_CHECK_HIP(hipGetDevice(&dev), name);
+  SERL_CHECK_ARG(dev >= 0 && dev < 64, "%s: device ordinal %d out of range", name, dev);
+  if (!opted[dev]) {
+    SERL_CHECK_HIP(hipFuncSetAttribute((const void*)pconv_fused12pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PFusedPPCfg::LDS + PFPP_TRACE_LDS), name);
+    SERL_CHECK_HIP(hipDeviceGetAttribute(&ncu[dev], hipDeviceAttributeMultiprocessorCount, dev), name);
+    opted[dev] = true;
+  }
+  const int nitems = a.B * a.nbands;
+  int gx = pconv_cus(ncu[dev]) / ngroups;
+  if (gx < 1) gx = 1;
+  if (gx > nitems) gx = nitems;
+  hipLaunchKernelGGL(pconv_fused12pp_kernel, dim3(gx, 1, ngroups), dim3(PFusedPPCfg::NT), PFusedPPCfg::LDS + PFPP_TRACE_LDS, st, a);
+  SERL_CHECK_LAUNCH(name);
+  return SERL_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ weight gradient
 // dW[ky][kx][c][f] = sum over (image, oy, ox) x[2 oy + ky][2 ox + kx][c] * dz[oy][ox][f], dbias[f] = sum dz, for the
 // 3x3 stride-2 layer with C = 32, F = 64.  The im2col kernel gathers its A operand (8 channels of one tap of one

@@ -297,12 +297,23 @@ def test_patch_conv_bit_identical_to_im2col(dev, case):
             np.testing.assert_allclose(b_, a_, rtol=0, atol=2e-5 * max(1.0, float(np.abs(a_).max())))
 
 
-@pytest.mark.parametrize("case", [(3, 128, 128, 9), (2, 100, 128, 9), (2, 128, 128, 3), (2, 31, 32, 8), (1, 7, 16, 3)])
-def test_convs_fwd12_bit_identical_to_two_launches(dev, case):
+@pytest.mark.parametrize("mode", [1, 4])        # two wave sets half a period apart (default) / one set
+@pytest.mark.parametrize("case", [(3, 128, 128, 9), (2, 100, 128, 9), (2, 128, 128, 3), (2, 31, 32, 8), (1, 7, 16, 3),
+                                  (24, 128, 128, 9), (45, 31, 32, 8), (70, 20, 48, 3)])
+def test_convs_fwd12_bit_identical_to_two_launches(dev, case, mode):
     """serl_convs_fwd12 (layers 1 + 2 of a no-gradient pass in one kernel, layer 1's output kept in LDS) against
     serl_convs_fwd(uint8) followed by serl_convs_fwd: same bits, same ReLU byte mask; full and ragged bands, 1..9 input
-    channels, an image smaller than one band."""
+    channels, an image smaller than one band, and batches large enough that a persistent block walks several items
+    (halo-row reuse, both wave sets, odd and even item counts)."""
     ops = _ops()
+    ops.convs_set_patch_kernels(mode)
+    try:
+        _fwd12_case(ops, dev, case)
+    finally:
+        ops.convs_set_patch_kernels(1)
+
+
+def _fwd12_case(ops, dev, case):
     B, IH1, IW1, C1 = case
     F1, F2, K, S, G = 32, 64, 3, 2, 3
     assert ops.convs_fwd12_supported(IH1, IW1, C1, F1, F2)
