@@ -80,6 +80,18 @@ __device__ __forceinline__ void pconv_lds_barrier() {
   __builtin_amdgcn_s_barrier();
 }
 
+// LDS reads by hand (pconv_fwdw_kernel, pconv_fused12pp_kernel): with an LDS-DMA in flight hipcc's wait-count pass treats lgkmcnt as unordered
+// (it models global_load_lds as a flat access) and turns every wait for an LDS read into lgkmcnt(0), i.e. it also waits
+// for the prefetches issued since.  These are issued and NOT waited for; the counted s_waitcnt that follows names the
+// registers as read-write operands, so no use can move above it.  Offsets are immediates.
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+#define PF_LD_D(d01, d2, addr, imm)                                                                                     \
+  asm volatile("ds_read2_b32 %0, %2 offset0:%3 offset1:%4\n\tds_read_b32 %1, %2 offset:%5"                               \
+               : "=&v"(d01), "=&v"(d2) : "v"(addr), "n"((imm) / 4), "n"((imm) / 4 + 1), "n"((imm) + 8) : "memory")
+#define PF_LD_2X128(o0, o1, a0, a1, imm0, imm1)                                                                         \
+  asm volatile("ds_read_b128 %0, %2 offset:%4\n\tds_read_b128 %1, %3 offset:%5"                                          \
+               : "=&v"(o0), "=&v"(o1) : "v"(a0), "v"(a1), "n"(imm0), "n"(imm1) : "memory")
+
 template <class G>
 __global__ __launch_bounds__(512, 1) void pconv_fwd_kernel(const PConvFwdArgs a) {
   constexpr int C = G::C, F = G::F, R = G::R, OWP = G::OWP, NT = G::NT;
@@ -438,41 +450,54 @@ __global__ __launch_bounds__(G::NT, 1) void pconv_fwdw_kernel(const PConvFwdArgs
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[m][q] = 0.f;
     // One wave per SIMD: nobody else hides this wave's LDS latency, so the A fragments of k16 step s + 1 are requested
-    // before the MFMAs of step s (pinned with sched_barrier), and the accumulators of the M tiles alternate so that no
-    // MFMA waits for the one issued just before it.
-    bf16x8_t fh[2][MT], fl[2][MT];
-    auto frags = [&](int s, int buf) {
-      const int tap = s / KS, kc = s - tap * KS;
-      const int ky = tap / 3, kx = tap - 3 * ky;
-      const int tapoff = ky * ROWB + (kx & 1) * PARB + (kx == 2 ? rec1 : rec0);
-      const int sw = kx == 2 ? sw1 : sw0;
-      const int chh = ((kc * 2 + h) << 4) ^ sw, chl = ((kc * 2 + h + C / 8) << 4) ^ sw;
+    // before the MFMAs of step s, and the accumulators of the M tiles alternate so that no MFMA waits for the one issued
+    // just before it.  The reads are written by hand with a COUNTED wait (PF_LD_2X128): left to hipcc every wait was
+    // lgkmcnt(0), i.e. every second step waited for the fragments it had just requested.
+    static_assert(NS == 36 && KS == 4 && MT == 2 && RPT == 2 && R == 4, "K loop unrolled by hand for C = 64, two M tiles");
+    u32x4_t fh[2][MT], fl[2][MT];
+    uint32_t pa[2][KS][2];                 // [kx == 2][kc][plane]: lane address in this item's patch; taps and the M tile are immediates
+    {
+      const uint32_t pl = (uint32_t)(size_t)(pconv_lptr_t)patch + (uint32_t)arow[0];
 #pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        fh[buf][m] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(patch + arow[m] + tapoff + chh));
-        fl[buf][m] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(patch + arow[m] + tapoff + chl));
-      }
-    };
-    frags(0, 0);
+      for (int x2 = 0; x2 < 2; ++x2)
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      const int cb = s & 1;
-      if (s + 1 < NS) frags(s + 1, cb ^ 1);
-      __builtin_amdgcn_sched_barrier(0);
+        for (int kc = 0; kc < KS; ++kc)
 #pragma unroll
-      for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl[cb][m], rbh[s], acc[m], 0, 0, 0);
-#pragma unroll
-      for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[cb][m], rbl[s], acc[m], 0, 0, 0);
-#pragma unroll
-      for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[cb][m], rbh[s], acc[m], 0, 0, 0);
-      // the next item's DMA pieces behind the first NDMA / 2 k16 steps (early: the patch has the rest of the item to land); branch-free (behind the last item the pieces
-      // copy zeros into the idle buffer): a branch here makes hipcc wait lgkmcnt(0) at the join, prefetch included
-      if (2 * s < NDMA) {
-        dma_piece(dn, npatch, 2 * s, more);
-        dma_piece(dn, npatch, 2 * s + 1, more);
-      }
-      __builtin_amdgcn_sched_barrier(0);
+          for (int p2 = 0; p2 < 2; ++p2)
+            pa[x2][kc][p2] = pl + (uint32_t)((x2 ? rec1 : rec0) + (((kc * 2 + h + p2 * (C / 8)) << 4) ^ (x2 ? sw1 : sw0)));
     }
+#define PW_IMM(s) (((s) / KS / 3) * ROWB + ((((s) / KS) % 3) & 1) * PARB)
+#define PW_LD(buf, s)                                                                                                   \
+    PF_LD_2X128(fh[buf][0], fl[buf][0], pa[((s) / KS) % 3 == 2][(s) % KS][0], pa[((s) / KS) % 3 == 2][(s) % KS][1], PW_IMM(s), PW_IMM(s)); \
+    PF_LD_2X128(fh[buf][1], fl[buf][1], pa[((s) / KS) % 3 == 2][(s) % KS][0], pa[((s) / KS) % 3 == 2][(s) % KS][1],     \
+                PW_IMM(s) + 4 * ROWB, PW_IMM(s) + 4 * ROWB);
+#define PW_STEP(s, CNT)                                                                                                 \
+    {                                                                                                                   \
+      if ((s) + 1 < NS) { PW_LD(((s) + 1) & 1, ((s) + 1) % NS) }                                                        \
+      asm volatile("s_waitcnt lgkmcnt(" #CNT ")"                                                                        \
+                   : "+v"(fh[(s) & 1][0]), "+v"(fl[(s) & 1][0]), "+v"(fh[(s) & 1][1]), "+v"(fl[(s) & 1][1]) : : "memory"); \
+      _Pragma("unroll") for (int m = 0; m < MT; ++m)                                                                    \
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fl[(s) & 1][m]), rbh[s], acc[m], 0, 0, 0); \
+      _Pragma("unroll") for (int m = 0; m < MT; ++m)                                                                    \
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fh[(s) & 1][m]), rbl[s], acc[m], 0, 0, 0); \
+      _Pragma("unroll") for (int m = 0; m < MT; ++m)                                                                    \
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fh[(s) & 1][m]), rbh[s], acc[m], 0, 0, 0); \
+      /* the next item's DMA pieces behind the first NDMA / 2 k16 steps (early: the patch has the rest of the item to */ \
+      /* land); branch-free (behind the last item the pieces copy zeros into the idle buffer) */                        \
+      if (2 * (s) < NDMA) {                                                                                             \
+        dma_piece(dn, npatch, 2 * (s), more);                                                                           \
+        dma_piece(dn, npatch, 2 * (s) + 1, more);                                                                       \
+      }                                                                                                                 \
+      __builtin_amdgcn_sched_barrier(0);                                                                                \
+    }
+    PW_LD(0, 0)
+    PW_STEP(0, 4) PW_STEP(1, 4) PW_STEP(2, 4) PW_STEP(3, 4) PW_STEP(4, 4) PW_STEP(5, 4) PW_STEP(6, 4) PW_STEP(7, 4) PW_STEP(8, 4)
+    PW_STEP(9, 4) PW_STEP(10, 4) PW_STEP(11, 4) PW_STEP(12, 4) PW_STEP(13, 4) PW_STEP(14, 4) PW_STEP(15, 4) PW_STEP(16, 4) PW_STEP(17, 4)
+    PW_STEP(18, 4) PW_STEP(19, 4) PW_STEP(20, 4) PW_STEP(21, 4) PW_STEP(22, 4) PW_STEP(23, 4) PW_STEP(24, 4) PW_STEP(25, 4) PW_STEP(26, 4)
+    PW_STEP(27, 4) PW_STEP(28, 4) PW_STEP(29, 4) PW_STEP(30, 4) PW_STEP(31, 4) PW_STEP(32, 4) PW_STEP(33, 4) PW_STEP(34, 4) PW_STEP(35, 0)
+#undef PW_STEP
+#undef PW_LD
+#undef PW_IMM
     pconv_lds_barrier();                   // every wave is done with the patch before the output tile overwrites it
 
     // ---- S-format output through an fp32 tile in LDS (as sgemm.h): 8 consecutive channels of one pixel per thread
@@ -1099,18 +1124,6 @@ static int pconv_fused12_launch(const PConvFusedArgs& a, int ngroups, hipStream_
   SERL_CHECK_LAUNCH(name);
   return SERL_OK;
 }
-
-// LDS reads of the two-set kernel, by hand: with an LDS-DMA in flight hipcc's wait-count pass treats lgkmcnt as unordered
-// (it models global_load_lds as a flat access) and turns every wait for an LDS read into lgkmcnt(0), i.e. it also waits
-// for the prefetches issued since.  These are issued and NOT waited for; the counted s_waitcnt that follows names the
-// registers as read-write operands, so no use can move above it.  Offsets are immediates.
-typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
-#define PF_LD_D(d01, d2, addr, imm)                                                                                     \
-  asm volatile("ds_read2_b32 %0, %2 offset0:%3 offset1:%4\n\tds_read_b32 %1, %2 offset:%5"                               \
-               : "=&v"(d01), "=&v"(d2) : "v"(addr), "n"((imm) / 4), "n"((imm) / 4 + 1), "n"((imm) + 8) : "memory")
-#define PF_LD_2X128(o0, o1, a0, a1, imm0, imm1)                                                                         \
-  asm volatile("ds_read_b128 %0, %2 offset:%4\n\tds_read_b128 %1, %3 offset:%5"                                          \
-               : "=&v"(o0), "=&v"(o1) : "v"(a0), "v"(a1), "n"(imm0), "n"(imm1) : "memory")
 
 // ------------------------------------------------------------------------------------------------ conv1 + conv2, two wave sets
 // pconv_fused12_kernel runs its phases one after the other on all 8 waves: the layer-1 phase is VALU work (uint8 ->
