@@ -67,9 +67,10 @@ int serl_convs_fwd(int ngroups, const void* const* x, const void* const* wf, con
  * serl_convs_dgrad masks dx with xact: the layer's post-ReLU input in S format (xact_bits = 0), or that byte mask
  * (xact_bits = 1); xact NULL or a NULL entry: no mask. */
 /* 3x3 stride-2 layers whose rows fit are run by the "patch" kernels (csrc/pconv.h: a band of input rows staged once in
- * LDS, all taps read from there; C = 64 -> F = 128 by four waves that hold the whole weight matrix in registers;
+ * LDS, all taps read from there; C = 64 <-> F = 128, forward and data gradient, by four waves that hold the whole
+ * weight matrix in registers;
  * bit-identical output).  enable = 0 keeps every layer on the im2col kernels -- for A/B measurements and the bit-identity
- * test of the paths; 2 = without the 4-wave kernel; 3 = plus the LDS-DMA ring GEMM (csrc/sgemm_ring.h) for the deep
+ * test of the paths; 2 = without the 4-wave kernels; 3 = plus the LDS-DMA ring GEMM (csrc/sgemm_ring.h) for the deep
  * layers; 4 = serl_convs_fwd12 on its one-set kernel (default: two wave sets half a period apart).  Process-wide; no counterpart in the reference (XLA picks its convolution algorithm itself,
  * two_d4pg_encoder.py:30-38). */
 int serl_convs_set_patch_kernels(int enable);

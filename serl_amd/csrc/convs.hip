@@ -703,8 +703,10 @@ extern "C" int serl_convs_dgrad(int ngroups, const void* const* dz, const void* 
   SERL_CHECK_ARG(F % 8 == 0 && C % 8 == 0, "convs_dgrad: need C %% 8 == 0 and F %% 8 == 0");
   SERL_CHECK_ARG(all_aligned16(dz, ngroups) && all_aligned16(wd, ngroups) && all_aligned16(dx, ngroups),
                  "convs_dgrad: S-format tensors must be 16-byte aligned");
-  if (g_patch_kernels && KH == 3 && KW == 3 && stride == 2 && C == 32 && F == 64 && g.OW <= 31 && IW <= 64 &&
-      (xact == nullptr || xact_bits)) {
+  const bool dg32 = C == 32 && F == 64 && g.OW <= 31 && IW <= 64;
+  // C = 64 <- F = 128 at OW <= 15: four waves with the weights of all four parity classes in their registers
+  const bool dg64 = g_wide_kernels && C == 64 && F == 128 && g.OW <= 15 && IW <= 32;
+  if (g_patch_kernels && KH == 3 && KW == 3 && stride == 2 && (dg32 || dg64) && (xact == nullptr || xact_bits)) {
     // dz rows staged once in LDS, all four parity classes computed from there (pconv.h); bit-identical output
     bool uniform = true;                // the byte mask is given for every group or for none
     if (xact != nullptr)
@@ -712,12 +714,14 @@ extern "C" int serl_convs_dgrad(int ngroups, const void* const* dz, const void* 
     if (uniform) {
       PConvDgradArgs a;
       a.B = B; a.IH = IH; a.IW = IW; a.OH = g.OH; a.OW = g.OW;
+      static_assert(PDgradCfg::P == PDgradWCfg::P, "band height");
       a.nbands = cdiv((IH + 1) / 2, PDgradCfg::P);
       a.d_bands = make_fastdiv(a.nbands);
       for (int i = 0; i < ngroups; ++i) {
         a.dz[i] = (const ushort_t*)dz[i]; a.wd[i] = (const ushort_t*)wd[i]; a.dx[i] = (ushort_t*)dx[i];
         a.xbits[i] = xact ? (const unsigned char*)xact[i] : nullptr;
       }
+      if (dg64) return pconv_dgradw_launch(a, ngroups, (hipStream_t)stream, "convs_dgrad(patch, wide)");
       return pconv_dgrad_launch(a, ngroups, (hipStream_t)stream, "convs_dgrad(patch)");
     }
   }

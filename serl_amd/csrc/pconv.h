@@ -565,9 +565,13 @@ static int pconv_fwdw_launch(const PConvFwdArgs& a, int ngroups, hipStream_t st,
     opted[dev] = true;
   }
   const int nitems = a.B * a.nbands;
-  int gx = pconv_cus(ncu[dev]) / ngroups;
+  static int cap = -1;                    // SERL_PCONV_FWDW_CUS: CUs this kernel spreads over (experiments with co-running streams)
+  if (cap < 0) { const char* e = getenv("SERL_PCONV_FWDW_CUS"); cap = e ? atoi(e) : 0; }
+  const int cus = pconv_cus(ncu[dev]);
+  int gx = (cap > 0 && cap < cus ? cap : cus) / ngroups;
   if (gx < 1) gx = 1;
   if (gx > nitems) gx = nitems;
+  gx = cdiv(nitems, cdiv(nitems, gx));
   hipLaunchKernelGGL((pconv_fwdw_kernel<G>), dim3(gx, 1, ngroups), dim3(G::NT), G::LDS, st, a);
   SERL_CHECK_LAUNCH(name);
   return SERL_OK;
@@ -832,6 +836,277 @@ static int pconv_dgrad_launch(const PConvDgradArgs& a, int ngroups, hipStream_t 
   if (gx < 1) gx = 1;
   if (gx > nitems) gx = nitems;
   hipLaunchKernelGGL(pconv_dgrad_kernel, dim3(gx, 1, ngroups), dim3(PDgradCfg::NT), PDgradCfg::LDS, st, a);
+  SERL_CHECK_LAUNCH(name);
+  return SERL_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ data gradient, wide layer
+// The same data gradient for C = 64, F = 128 (third layer of the encoder: dz 15 x 15 x 128 -> dx 31 x 31 x 64).  The
+// im2col kernel fetched 4.7x the bytes of dz here (profiles/r02_v4_traffic.json).  The weights of all four parity classes
+// (9 taps x 64 x 128 x 2 planes = 295 KB) do not fit the registers of an 8-wave block, so -- as in pconv_fwdw_kernel --
+// FOUR waves, one per SIMD, each with the SIMD's whole register budget: wave (nh, cg) owns output channels
+// [32 nh, 32 nh + 32) of class (0,0) (cg = 0: 4 taps, K = 512, 256 registers of B fragments) or of classes (0,1), (1,0),
+// (1,1) (cg = 1: K = 256 + 256 + 128, 320 registers): 32 : 40 k16 steps per M tile.  An item is a band of P = 4 input
+// row pairs of one image (P + 1 rows of dz, 512-byte records, 16 per row: record 15 and the rows outside the image
+// are zeros); per class it has 4 x 16 pixels = two M tiles (tile m: row pairs 2m, 2m + 1; lane r: column pair r & 15 of
+// row pair 2m + (r >> 4)), multiplied together with alternating accumulators and the A fragments one k16 step ahead.
+// Same k order (jy, jx, f) and MFMA sequence per output as sgemm_kernel<ConvDgradS>: bit-identical.
+struct PDgradWCfg {
+  static constexpr int C = 64, F = 128, P = 4, NW = 4, NT = 64 * NW;
+  static constexpr int REC = 4 * F, NCH = F / 4;          // 512-byte records, 32 chunks
+  static constexpr int ROWB = 16 * REC;
+  static constexpr int PATCH = (P + 1) * ROWB;
+  static constexpr int SLOTS = PATCH / 16, NDMA = SLOTS / NT;
+  static constexpr int CSLD = 32 + 4, CSB = 32 * CSLD * 4;  // wave-private output tile (32 pixels x 32 channels)
+  static constexpr int MSB = 2 * P * 32 * (C / 8);        // mask bytes of one item: 2P rows x (IW <= 32) pixels x C/8
+  static constexpr int LDS = 2 * PATCH + NW * CSB + 2 * MSB;
+  static_assert(SLOTS % NT == 0 && MSB == 2 * NW * 256 && LDS <= 160 * 1024, "LDS");
+};
+
+// B fragments of class (PY, PX) for output channels [32 nh, 32 nh + 32): lane (r, h) holds f = 16 kc + 8 h .. + 7 of tap t
+template <int PY, int PX>
+__device__ __forceinline__ void pdgradw_load_b(const unsigned short* wd, int nh, int r, int h, bf16x8_t* bh, bf16x8_t* bl) {
+  constexpr int TY = PY ? 1 : 2, TX = PX ? 1 : 2, C = PDgradWCfg::C, F = PDgradWCfg::F, KC = F / 16;
+#pragma unroll
+  for (int jy = 0; jy < TY; ++jy)
+#pragma unroll
+    for (int jx = 0; jx < TX; ++jx) {
+      const int tap = (PY + 2 * jy) * 3 + (PX + 2 * jx);
+      const unsigned short* row = wd + (size_t)((tap * C + nh * 32 + r) * 2) * F + h * 8;
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc) {
+        bh[(jy * TX + jx) * KC + kc] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(row + kc * 16));
+        bl[(jy * TX + jx) * KC + kc] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(row + F + kc * 16));
+      }
+    }
+}
+
+// K loop of both M tiles of class (PY, PX)
+template <int PY, int PX>
+__device__ __forceinline__ void pdgradw_tiles(const unsigned char* patch, int r, int h, const bf16x8_t* bh,
+                                              const bf16x8_t* bl, f32x16 (&acc)[2]) {
+  constexpr int TY = PY ? 1 : 2, TX = PX ? 1 : 2, KC = PDgradWCfg::F / 16, NSTEP = TY * TX * KC;
+  constexpr int ROWB = PDgradWCfg::ROWB, REC = PDgradWCfg::REC;
+  const int ixp = r & 15, rp = r >> 4;
+  bf16x8_t fh[2][2], fl[2][2];
+  auto frags = [&](int s, int buf) {
+    const int t = s / KC, kc = s - t * KC;
+    const int jy = t / TX, jx = t - jy * TX;
+    const int rec = (ixp - jx) & 15;
+    const unsigned char* base = patch + (rp - jy + 1) * ROWB + rec * REC;
+    const int sw = rec << 4;
+    const int chh = ((kc * 2 + h) << 4) ^ sw, chl = ((kc * 2 + h + PDgradWCfg::F / 8) << 4) ^ sw;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      fh[buf][m] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(base + m * 2 * ROWB + chh));
+      fl[buf][m] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(base + m * 2 * ROWB + chl));
+    }
+  };
+  frags(0, 0);
+#pragma unroll
+  for (int s = 0; s < NSTEP; ++s) {
+    const int cb = s & 1;
+    if (s + 1 < NSTEP) frags(s + 1, cb ^ 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl[cb][m], bh[s], acc[m], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[cb][m], bl[s], acc[m], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[cb][m], bh[s], acc[m], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// M tile mt of class (PY, PX) out (pdgrad_store's path: wave-private fp32 tile, byte mask from LDS, two 16-byte stores
+// per pass, lanes without a valid pixel store to g_pconv_dump so that every wave issues the same number of stores)
+template <int PY, int PX>
+__device__ __forceinline__ void pdgradw_store(const PConvDgradArgs& a, int z, int b, int band, int mt, int nh, float* Cs,
+                                              uint32_t cs_base, uint32_t ms_base, bool masked, const f32x16& acc, int lane) {
+  constexpr int C = PDgradWCfg::C, LD = PDgradWCfg::CSLD, P = PDgradWCfg::P;
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) Cs[((q & 3) + 8 * (q >> 2) + 4 * h) * LD + r] = acc[q];
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int u = lane + 64 * pass, pxl = u >> 2, ch = u & 3;
+    const int rp = 2 * mt + (pxl >> 4);
+    const int iy = 2 * (band * P + rp) + PY, ix = 2 * (pxl & 15) + PX;
+    const bool ok = iy < a.IH && ix < a.IW;
+    u32x4_t c0, c1;
+    uint32_t bits = 0xffu;
+    if (masked) {
+      const uint32_t maddr = ms_base + (ok ? (uint32_t)(((2 * rp + PY) * a.IW + ix) * (C >> 3) + nh * 4 + ch) : 0u);
+      asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:16\n\tds_read_u8 %2, %4\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&v"(c0), "=&v"(c1), "=&v"(bits) : "v"(cs_base + (uint32_t)(pxl * LD + ch * 8) * 4u), "v"(maddr) : "memory");
+    } else {
+      asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&v"(c0), "=&v"(c1) : "v"(cs_base + (uint32_t)(pxl * LD + ch * 8) * 4u) : "memory");
+    }
+    float v[8] = {__uint_as_float(c0[0]), __uint_as_float(c0[1]), __uint_as_float(c0[2]), __uint_as_float(c0[3]),
+                  __uint_as_float(c1[0]), __uint_as_float(c1[1]), __uint_as_float(c1[2]), __uint_as_float(c1[3])};
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (!(bits & (1u << j))) v[j] = 0.f;
+    u32x4_t hi, lo;
+    uint32_t hh, ll;
+    split_pair(v[0], v[1], hh, ll); hi[0] = hh; lo[0] = ll;
+    split_pair(v[2], v[3], hh, ll); hi[1] = hh; lo[1] = ll;
+    split_pair(v[4], v[5], hh, ll); hi[2] = hh; lo[2] = ll;
+    split_pair(v[6], v[7], hh, ll); hi[3] = hh; lo[3] = ll;
+    unsigned short* dst = ok ? a.dx[z] + ((size_t)(b * a.IH + iy) * a.IW + ix) * 2 * C + nh * 32 + ch * 8
+                             : reinterpret_cast<unsigned short*>(g_pconv_dump) + lane * 32;
+    *reinterpret_cast<u32x4_t*>(dst) = hi;
+    *reinterpret_cast<u32x4_t*>(dst + C) = lo;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the tile is reused by this wave's next M tile
+}
+
+__global__ __launch_bounds__(256, 1) void pconv_dgradw_kernel(const PConvDgradArgs a) {
+  typedef PDgradWCfg G;
+  constexpr int P = G::P, NW = G::NW, NDMA = G::NDMA;
+  extern __shared__ __attribute__((aligned(16))) unsigned char p_smem[];
+  const int z = blockIdx.z;
+  const int nitems = a.B * a.nbands;
+  const int per = (nitems + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int it0 = blockIdx.x * per, it1 = min(nitems, it0 + per);
+  if (it0 >= it1) return;
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int nh = wid & 1;                   // half of the output channels
+  const bool type_x = (wid >> 1) == 0;      // class (0,0) | classes (0,1), (1,0), (1,1)
+  float* const Cs = reinterpret_cast<float*>(p_smem + 2 * G::PATCH + wid * G::CSB);
+  const uint32_t cs_base = (uint32_t)(size_t)(pconv_lptr_t)Cs;
+  unsigned char* const Ms = p_smem + 2 * G::PATCH + NW * G::CSB;         // [2][MSB] mask bytes of the item's 2P rows
+  const uint32_t ms_base0 = (uint32_t)(size_t)(pconv_lptr_t)Ms;
+  const bool masked = a.xbits[z] != nullptr;
+
+  struct DmaSrc { const char* dz; const char* mk; int oy_first, mk_bytes; };
+  auto dma_src = [&](int item) {
+    const int b = (int)fd_div((uint32_t)item, a.d_bands), band = item - b * a.nbands;
+    DmaSrc d;
+    d.oy_first = band * P - 1;              // dz row of patch row 0
+    d.dz = reinterpret_cast<const char*>(a.dz[z]) + (size_t)b * a.OH * a.OW * G::REC;
+    d.mk = reinterpret_cast<const char*>(a.xbits[z]) + ((size_t)(b * a.IH + 2 * P * band) * a.IW) * (G::C / 8);
+    d.mk_bytes = max(0, min(2 * P, a.IH - 2 * P * band)) * a.IW * (G::C / 8);
+    return d;
+  };
+  auto dma_mask = [&](const DmaSrc& d, int buf) {           // two rounds of 4 waves x 256 bytes
+    if (!masked) return;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int off = (i * NW + wid) * 256 + lane * 4;
+      const char* g = off < d.mk_bytes ? d.mk + off : reinterpret_cast<const char*>(g_zero_page);
+      __builtin_amdgcn_global_load_lds((pconv_gptr_t)g, (pconv_lptr_t)(Ms + buf * G::MSB + (i * NW + wid) * 256), 4, 0, 0);
+    }
+  };
+  auto dma_piece = [&](const DmaSrc& d, unsigned char* patch, int i) {
+    const int l = (i * NW + wid) * 64 + lane;
+    const int rec = l >> 5, chp = l & 31;
+    const int row = rec >> 4, ox = rec & 15, oy = d.oy_first + row;
+    const bool ok = oy >= 0 && oy < a.OH && ox < a.OW;
+    const char* g = ok ? d.dz + (size_t)(((oy * a.OW + ox) << 5) + (chp ^ ox)) * 16
+                       : reinterpret_cast<const char*>(g_zero_page);
+    __builtin_amdgcn_global_load_lds((pconv_gptr_t)g, (pconv_lptr_t)(patch + (i * NW + wid) * 1024), 16, 0, 0);
+  };
+  {
+    const DmaSrc d0 = dma_src(it0);
+#pragma unroll 1
+    for (int i = 0; i < NDMA; ++i) dma_piece(d0, p_smem, i);
+    dma_mask(d0, 0);
+  }
+
+  if (type_x) {
+    bf16x8_t bh[32], bl[32];
+    pdgradw_load_b<0, 0>(a.wd[z], nh, r, h, bh, bl);
+    int pb = 0;
+    for (int item = it0; item < it1; ++item, pb ^= 1) {
+      const unsigned char* patch = p_smem + pb * G::PATCH;
+      unsigned char* npatch = p_smem + (pb ^ 1) * G::PATCH;
+      const int b = (int)fd_div((uint32_t)item, a.d_bands), band = item - b * a.nbands;
+      // this item's patch has landed; the stores of the previous item (2 M tiles x 4 per wave of this type) are younger
+      // than its DMA and vmcnt retires in order, so they stay in flight
+      if (item == it0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      const bool more = item + 1 < it1;
+      const DmaSrc dn = dma_src(more ? item + 1 : item);
+      if (more) {
+#pragma unroll
+        for (int i = 0; i < NDMA; ++i) dma_piece(dn, npatch, i);
+        dma_mask(dn, pb ^ 1);
+      }
+      const uint32_t ms_base = ms_base0 + pb * G::MSB;
+      f32x16 acc[2];
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[m][q] = 0.f;
+      pdgradw_tiles<0, 0>(patch, r, h, bh, bl, acc);
+      pdgradw_store<0, 0>(a, z, b, band, 0, nh, Cs, cs_base, ms_base, masked, acc[0], lane);
+      pdgradw_store<0, 0>(a, z, b, band, 1, nh, Cs, cs_base, ms_base, masked, acc[1], lane);
+    }
+  } else {
+    bf16x8_t bh[40], bl[40];
+    pdgradw_load_b<0, 1>(a.wd[z], nh, r, h, bh, bl);
+    pdgradw_load_b<1, 0>(a.wd[z], nh, r, h, bh + 16, bl + 16);
+    pdgradw_load_b<1, 1>(a.wd[z], nh, r, h, bh + 32, bl + 32);
+    int pb = 0;
+    for (int item = it0; item < it1; ++item, pb ^= 1) {
+      const unsigned char* patch = p_smem + pb * G::PATCH;
+      unsigned char* npatch = p_smem + (pb ^ 1) * G::PATCH;
+      const int b = (int)fd_div((uint32_t)item, a.d_bands), band = item - b * a.nbands;
+      if (item == it0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)" ::: "memory");      // 3 classes x 2 M tiles x 4 stores
+      __builtin_amdgcn_s_barrier();
+      const bool more = item + 1 < it1;
+      const DmaSrc dn = dma_src(more ? item + 1 : item);
+      if (more) {
+#pragma unroll
+        for (int i = 0; i < NDMA; ++i) dma_piece(dn, npatch, i);
+        dma_mask(dn, pb ^ 1);
+      }
+      const uint32_t ms_base = ms_base0 + pb * G::MSB;
+      f32x16 acc[2];
+#define PDGW_CLASS(PY, PX, OFF)                                                                                         \
+      _Pragma("unroll") for (int m = 0; m < 2; ++m)                                                                     \
+        _Pragma("unroll") for (int q = 0; q < 16; ++q) acc[m][q] = 0.f;                                                 \
+      pdgradw_tiles<PY, PX>(patch, r, h, bh + OFF, bl + OFF, acc);                                                      \
+      pdgradw_store<PY, PX>(a, z, b, band, 0, nh, Cs, cs_base, ms_base, masked, acc[0], lane);                          \
+      pdgradw_store<PY, PX>(a, z, b, band, 1, nh, Cs, cs_base, ms_base, masked, acc[1], lane);
+      PDGW_CLASS(0, 1, 0)
+      PDGW_CLASS(1, 0, 16)
+      PDGW_CLASS(1, 1, 32)
+#undef PDGW_CLASS
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no DMA may still be landing when the block's LDS is handed on
+}
+
+static int pconv_dgradw_launch(const PConvDgradArgs& a, int ngroups, hipStream_t st, const char* name) {
+  static bool opted[64] = {};
+  static int ncu[64] = {};
+  int dev = 0;
+  SERL_CHECK_HIP(hipGetDevice(&dev), name);
+  SERL_CHECK_ARG(dev >= 0 && dev < 64, "%s: device ordinal %d out of range", name, dev);
+  if (!opted[dev]) {
+    SERL_CHECK_HIP(hipFuncSetAttribute((const void*)pconv_dgradw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PDgradWCfg::LDS), name);
+    SERL_CHECK_HIP(hipDeviceGetAttribute(&ncu[dev], hipDeviceAttributeMultiprocessorCount, dev), name);
+    opted[dev] = true;
+  }
+  const int nitems = a.B * a.nbands;
+  // A block of this kernel takes its CU's whole register file, so on every CU it runs on the other streams of the
+  // update (weight gradients, the actor's run-ahead pass) stand still: three quarters of the CUs measured best inside
+  // the update (588 -> 591 grad-steps/s; all CUs: 584, i.e. slower than the im2col kernel it replaces, although it is
+  // 15 % faster alone).  SERL_PCONV_DGW_CUS overrides the count.  Blocks get equal item counts.
+  static int cap = -1;
+  if (cap < 0) { const char* e = getenv("SERL_PCONV_DGW_CUS"); cap = e ? atoi(e) : 0; }
+  const int cus = pconv_cus(ncu[dev]);
+  int gx = (cap > 0 ? (cap < cus ? cap : cus) : cus * 3 / 4) / ngroups;
+  if (gx < 1) gx = 1;
+  if (gx > nitems) gx = nitems;
+  gx = cdiv(nitems, cdiv(nitems, gx));
+  hipLaunchKernelGGL(pconv_dgradw_kernel, dim3(gx, 1, ngroups), dim3(PDgradWCfg::NT), PDgradWCfg::LDS, st, a);
   SERL_CHECK_LAUNCH(name);
   return SERL_OK;
 }

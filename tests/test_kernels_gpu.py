@@ -229,7 +229,8 @@ def test_convs_fwd_dgrad_wgrad(dev, case):
 
 
 @pytest.mark.parametrize("case", [(3, 63, 63, 32, 64), (2, 64, 63, 32, 64), (3, 31, 31, 64, 128), (2, 29, 32, 64, 128),
-                                  (1, 9, 11, 32, 64), (6, 15, 15, 128, 256), (1, 16, 13, 128, 256), (1, 7, 7, 64, 136)])
+                                  (1, 9, 11, 32, 64), (6, 15, 15, 128, 256), (1, 16, 13, 128, 256), (1, 7, 7, 64, 136),
+                                  (40, 31, 31, 64, 128), (30, 13, 9, 64, 128)])
 def test_patch_conv_bit_identical_to_im2col(dev, case):
     """The LDS-patch kernels (csrc/pconv.h) and the LDS-DMA ring GEMM (csrc/sgemm_ring.h, layers with F >= 128) keep the
     k order and the MFMA sequence of the im2col kernels: outputs, ReLU byte masks and data gradients must be
