@@ -832,9 +832,13 @@ static int pconv_dgrad_launch(const PConvDgradArgs& a, int ngroups, hipStream_t 
     opted[dev] = true;
   }
   const int nitems = a.B * a.nbands;
-  int gx = pconv_cus(ncu[dev]) / ngroups;
+  static int cap = -1;                    // SERL_PCONV_DG_CUS: CUs this kernel spreads over (experiments with co-running streams)
+  if (cap < 0) { const char* e = getenv("SERL_PCONV_DG_CUS"); cap = e ? atoi(e) : 0; }
+  const int cus = pconv_cus(ncu[dev]);
+  int gx = (cap > 0 && cap < cus ? cap : cus) / ngroups;
   if (gx < 1) gx = 1;
   if (gx > nitems) gx = nitems;
+  gx = cdiv(nitems, cdiv(nitems, gx));
   hipLaunchKernelGGL(pconv_dgrad_kernel, dim3(gx, 1, ngroups), dim3(PDgradCfg::NT), PDgradCfg::LDS, st, a);
   SERL_CHECK_LAUNCH(name);
   return SERL_OK;
