@@ -155,7 +155,8 @@ struct serl_learner {
   Workspace ws_act;
   std::mutex act_mu;
   hipStream_t s1 = nullptr, astream = nullptr;
-  GradSide gside;
+  GradSide gside, gside2;   // gside2: every other conv weight gradient (SERL_AMD_WG_STREAMS=2), so that it starts when its dz is ready
+  int wg_streams = getenv("SERL_AMD_WG_STREAMS") ? atoi(getenv("SERL_AMD_WG_STREAMS")) : 1;
   hipEvent_t fork_ev = nullptr, join1 = nullptr, astart = nullptr, agate = nullptr, aobs = nullptr;
   std::vector<hipEvent_t> adone;
   const float* backbone = nullptr;   // frozen MobileNetV3 parameters (serl_learner_set_backbone)
@@ -458,8 +459,16 @@ int encoder_bwd(serl_learner* h, char tag, const Store& store, const EncOff& eo,
     // which becomes ready last, runs on the main stream behind the last data gradient (its own slabs).
     const bool on_main = gside && li < h->wg_main_layers && nl > 1;
     hipStream_t sw = st;
-    if (gside && !on_main) DRV(gside->fork(&sw));   // dz of this layer is ready on the main stream here
     float* slab_l = slab;
+    if (gside && !on_main) {                        // dz of this layer is ready on the main stream here
+      if (gside == &h->gside && h->wg_streams > 1 && ((nl - 1 - li) & 1)) {
+        DRV(h->gside2.fork(&sw));
+        WSF(ws, st, slab2, (size_t)slab_bytes / 4, "wgrad_slab2");
+        slab_l = slab2;
+      } else {
+        DRV(gside->fork(&sw));
+      }
+    }
     if (on_main) {
       WSF(ws, st, slab1, (size_t)slab_bytes / 4, "wgrad_slab_main");
       slab_l = slab1;
@@ -1127,6 +1136,7 @@ extern "C" int serl_learner_create(const serl_learner_config* pc, const long lon
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->s1, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->astream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->gside.own, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->gside2.own, hipStreamNonBlocking);
   hipEvent_t* evs[] = {&h->fork_ev, &h->join1, &h->astart, &h->agate, &h->aobs};
   for (hipEvent_t* ev : evs)
     if (e == hipSuccess) e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
@@ -1155,6 +1165,8 @@ extern "C" int serl_learner_destroy(serl_learner* h) {
   if (h->astream) (void)hipStreamDestroy(h->astream);
   if (h->gside.own) (void)hipStreamDestroy(h->gside.own);
   for (hipEvent_t e : h->gside.ev) (void)hipEventDestroy(e);
+  if (h->gside2.own) (void)hipStreamDestroy(h->gside2.own);
+  for (hipEvent_t e : h->gside2.ev) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->adone) (void)hipEventDestroy(e);
   for (hipEvent_t e : {h->fork_ev, h->join1, h->astart, h->agate, h->aobs})
     if (e) (void)hipEventDestroy(e);
@@ -1317,6 +1329,7 @@ extern "C" int serl_learner_update(serl_learner* h, const serl_agent_buffers* ag
                      log_temp, c.discount, q, E, B, 1.0f / ((float)E * Bg), target_q, dq, info, st));
     DRV(phase(h, "heads_fwd", st));
     h->gside.begin(st, multi);
+    h->gside2.begin(st, multi);
     // pixel learners: the trunk backward sums the split-K slabs of the input gradient on read; state-based:
     // observations are not trainable, the critic step needs no input gradient at all
     float* dinp = nullptr; int nslab = 1; long long ss = 0;
@@ -1324,6 +1337,7 @@ extern "C" int serl_learner_update(serl_learner* h, const serl_agent_buffers* ag
     DRV(phase(h, "ensemble_bwd", st));
     DRV(features_bwd(h, 'C', critic, co.e, cgr, f, lo, B, ws, st, dinp, ldz, true, &h->gside, nslab, ss, &step_keys[8 * i + 6]));
     DRV(h->gside.join());
+    DRV(h->gside2.join());
     DRV(phase(h, "features_bwd", st));
     if (world > 1) DRV(allreduce(allreduce_ctx, 0));   // data parallel: one all-reduce(sum) of the flat gradient per step
     ++critic_step;
