@@ -74,6 +74,10 @@ int serl_convs_fwd(int ngroups, const void* const* x, const void* const* wf, con
  * layers; 4 = serl_convs_fwd12 on its one-set kernel (default: two wave sets half a period apart).  Process-wide; no counterpart in the reference (XLA picks its convolution algorithm itself,
  * two_d4pg_encoder.py:30-38). */
 int serl_convs_set_patch_kernels(int enable);
+/* Persistent patch kernels launched after this call spread over at most `cus` compute units (0: all).  The step driver
+ * brackets the actor's run-ahead pass with it (SERL_AMD_ACTOR_CUS).  Process-wide, not synchronised; no counterpart in
+ * the reference. */
+int serl_convs_set_cu_limit(int cus);
 /* Layers 1 + 2 of a NO-GRADIENT encoder pass (target critic, actor: two_d4pg_encoder.py:30-38 under stop_gradient /
  * in the target network) in one launch: uint8 frames [B][IH1][IW1][C1] -> 3x3 stride-2 conv (-> F1 = 32) + bias + ReLU ->
  * 3x3 stride-2 conv (-> F2 = 64) + bias [+ ReLU] -> y (S format); wf1 / wf2 as serl_convs_prep_weights writes them

@@ -592,6 +592,14 @@ extern "C" int serl_convs_set_patch_kernels(int enable) {
   return SERL_OK;
 }
 
+// Persistent patch kernels launched after this call spread over at most `cus` CUs (0: all).  The driver brackets the
+// actor's run-ahead pass with it: its persistent blocks otherwise hold every CU for ~100 us at a time, and the short
+// kernels of the critic step's latency-bound chain wait for one to retire.  Process-wide, not synchronised.
+extern "C" int serl_convs_set_cu_limit(int cus) {
+  g_pconv_cu_limit = cus > 0 ? cus : 0;
+  return SERL_OK;
+}
+
 #ifndef S_RING_FWD
 #define S_RING_FWD RingCfg<256, 128, 4, 2, 3>     // 8 waves, 64 x 64 per wave, three K slabs of 32 in flight
 #endif

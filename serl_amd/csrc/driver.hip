@@ -156,6 +156,10 @@ struct serl_learner {
   std::mutex act_mu;
   hipStream_t s1 = nullptr, astream = nullptr;
   GradSide gside, gside2;   // gside2: every other conv weight gradient (SERL_AMD_WG_STREAMS=2), so that it starts when its dz is ready
+  // CU cap of the run-ahead pass's persistent patch kernels (default 7/8 of the CUs, set at creation; 0: none).  Their
+  // blocks otherwise hold every CU for ~100 us at a time and the short kernels of the critic step's latency-bound chain
+  // wait for one to retire: 592.9 -> 596.5 grad-steps/s at 224 of 256 (three interleaved runs; 240: -0.3 %, 208: +0.2 %).
+  int actor_cus = getenv("SERL_AMD_ACTOR_CUS") ? atoi(getenv("SERL_AMD_ACTOR_CUS")) : -1;
   int wg_streams = getenv("SERL_AMD_WG_STREAMS") ? atoi(getenv("SERL_AMD_WG_STREAMS")) : 1;
   hipEvent_t fork_ev = nullptr, join1 = nullptr, astart = nullptr, agate = nullptr, aobs = nullptr;
   std::vector<hipEvent_t> adone;
@@ -1137,6 +1141,11 @@ extern "C" int serl_learner_create(const serl_learner_config* pc, const long lon
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->astream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->gside.own, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->gside2.own, hipStreamNonBlocking);
+  if (e == hipSuccess && h->actor_cus < 0) {
+    int ncu = 0;
+    e = hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->device);
+    h->actor_cus = ncu * 7 / 8;
+  }
   hipEvent_t* evs[] = {&h->fork_ev, &h->join1, &h->astart, &h->agate, &h->aobs};
   for (hipEvent_t* ev : evs)
     if (e == hipSuccess) e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
@@ -1279,7 +1288,10 @@ extern "C" int serl_learner_update(serl_learner* h, const serl_agent_buffers* ag
                         rank * B, Bg, zT_all + ((size_t)j * B * ldz + c.latent), ldz, false, false, c.backup_entropy != 0,
                         nlogp_all + (size_t)j * B, nullptr);
     FPass p{'A', actor, &ao.e, 1, zA, sta};
-    DRV(features(h, &p, 1, f, j * B, B, ws, sta, 0, nullptr, j == 0));   // S-format weight copies made once (j == 0)
+    if (sta != st) (void)serl_convs_set_cu_limit(h->actor_cus);
+    const int fe = features(h, &p, 1, f, j * B, B, ws, sta, 0, nullptr, j == 0);   // S-format weight copies made once (j == 0)
+    (void)serl_convs_set_cu_limit(0);
+    DRV(fe);
     DRV(policy_fwd(h, 'A', actor, ao, zA, ldz, B, ws, sta, &step_keys[8 * j], rank * B, Bg,
                    zT_all + ((size_t)j * B * ldz + c.latent), ldz, false, false, c.backup_entropy != 0,
                    nlogp_all + (size_t)j * B, nullptr));
@@ -1291,7 +1303,10 @@ extern "C" int serl_learner_update(serl_learner* h, const serl_agent_buffers* ag
       return policy_fwd(h, 'A', actor, ao, f.obs + (size_t)(utd - 1) * B * c.obs_dim, c.obs_dim, B, ws, sta, key_pi, rank * B,
                         Bg, zP + c.latent, ldz, false, true, true, logpA, nullptr);
     FPass p{'A', actor, &ao.e, 0, zA, sta};
-    DRV(features(h, &p, 1, f, (utd - 1) * B, B, ws, sta, 'A', nullptr, false));
+    if (sta != st) (void)serl_convs_set_cu_limit(h->actor_cus);
+    const int fe = features(h, &p, 1, f, (utd - 1) * B, B, ws, sta, 'A', nullptr, false);
+    (void)serl_convs_set_cu_limit(0);
+    DRV(fe);
     DRV(policy_fwd(h, 'A', actor, ao, zA, ldz, B, ws, sta, key_pi, rank * B, Bg, zP + c.latent, ldz, false, true, true, logpA,
                    nullptr));
     if (sta != st) DRV_HIP(hipEventRecord(h->aobs, sta));

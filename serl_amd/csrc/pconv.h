@@ -62,10 +62,12 @@ struct PFwdCfg {
 };
 
 // CUs a persistent grid spreads over (all of them; SERL_PCONV_CUS caps it for experiments with co-running streams)
+static int g_pconv_cu_limit = 0;        // serl_convs_set_cu_limit: a caller-set cap for the launches that follow (0: none)
 static int pconv_cus(int ncu) {
   static int cap = -1;
   if (cap < 0) { const char* e = getenv("SERL_PCONV_CUS"); cap = e ? atoi(e) : 0; }
-  const int n = ncu > 0 ? ncu : 256;
+  int n = ncu > 0 ? ncu : 256;
+  if (g_pconv_cu_limit > 0 && g_pconv_cu_limit < n) n = g_pconv_cu_limit;
   return cap > 0 && cap < n ? cap : n;
 }
 
