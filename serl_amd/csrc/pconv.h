@@ -1973,7 +1973,10 @@ static int pconv_wgrad_launch(PConvWgradArgs& a, int ngroups, long long workspac
     opted[dev] = true;
   }
   const int nitems = a.B * a.nbands;
-  int gx = pconv_cus(ncu[dev]) / ngroups;
+  static int cap = -1;                    // SERL_PCONV_WG_CUS: CUs this kernel spreads over (experiments with co-running streams)
+  if (cap < 0) { const char* e = getenv("SERL_PCONV_WG_CUS"); cap = e ? atoi(e) : 0; }
+  const int cus = pconv_cus(ncu[dev]);
+  int gx = (cap > 0 && cap < cus ? cap : cus) / ngroups;
   const long long fit = workspace_bytes / ((long long)ngroups * PWgradCfg::SLAB * 4);
   if (gx > fit) gx = (int)fit;
   if (gx > nitems) gx = nitems;
