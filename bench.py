@@ -163,6 +163,9 @@ def main():
     rehearsal = os.environ.get("SERL_AMD_BENCH_REHEARSAL", "0") != "0"
     if rehearsal:
         local_rank = 0
+        if os.environ.get("REH_DUMP_AFTER"):     # a stalled rank prints the stacks of all its threads and exits
+            import faulthandler
+            faulthandler.dump_traceback_later(int(os.environ["REH_DUMP_AFTER"]), exit=True)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local_rank)
     dist = None

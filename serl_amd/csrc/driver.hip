@@ -1140,7 +1140,8 @@ extern "C" int serl_learner_create(const serl_learner_config* pc, const long lon
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->s1, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->astream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->gside.own, hipStreamNonBlocking);
-  if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->gside2.own, hipStreamNonBlocking);
+  // (only when asked for: a process has GPU_MAX_HW_QUEUES = 4 hardware queues, a fifth stream shares one with another)
+  if (e == hipSuccess && h->wg_streams > 1) e = hipStreamCreateWithFlags(&h->gside2.own, hipStreamNonBlocking);
   if (e == hipSuccess && h->actor_cus < 0) {
     int ncu = 0;
     e = hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->device);
@@ -1344,7 +1345,7 @@ extern "C" int serl_learner_update(serl_learner* h, const serl_agent_buffers* ag
                      log_temp, c.discount, q, E, B, 1.0f / ((float)E * Bg), target_q, dq, info, st));
     DRV(phase(h, "heads_fwd", st));
     h->gside.begin(st, multi);
-    h->gside2.begin(st, multi);
+    h->gside2.begin(st, multi && h->wg_streams > 1);
     // pixel learners: the trunk backward sums the split-K slabs of the input gradient on read; state-based:
     // observations are not trainable, the critic step needs no input gradient at all
     float* dinp = nullptr; int nslab = 1; long long ss = 0;

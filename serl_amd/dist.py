@@ -20,6 +20,12 @@ class DataParallel:
 
     def all_reduce_sum(self, tensor):
         if self.world_size > 1:
+            if tensor.is_cuda and self._td.get_backend(self.group) == "gloo":
+                # gloo stages a device tensor through the host.  With the update's kernels still queued behind it the
+                # collective stalled for minutes, now and then (two ranks on one GPU, tools/rehearse_dp.sh); with the
+                # device idle it takes milliseconds.  RCCL ("nccl") enqueues on the stream and needs no such wait.
+                import torch
+                torch.cuda.synchronize(tensor.device)
             self._td.all_reduce(tensor, op=self._td.ReduceOp.SUM, group=self.group)
         return tensor
 

@@ -6,12 +6,16 @@ C-ABI call that enqueues the whole update; `act()` one call per action."""
 from __future__ import annotations
 
 import ctypes as C
+import os
+import sys
 
 import numpy as np
 import torch
 
 from . import _lib
 from .networks.spec import NetConfig, actor_layout, critic_layout
+
+_DP_TRACE = os.environ.get("SERL_AMD_DP_TRACE", "0") != "0"     # a stderr line around every all-reduce of update()
 
 c_fp = C.POINTER(C.c_float)
 
@@ -129,7 +133,11 @@ class NativeLearner:
                     if which == 3:
                         features_hook()
                     else:
+                        if _DP_TRACE:
+                            print(f"[dp rank {rank}] all-reduce {which} ({reduce_tensors[which].numel()} elements) ...", file=sys.stderr, flush=True)
                         dist.all_reduce_sum(reduce_tensors[which])
+                        if _DP_TRACE:
+                            print(f"[dp rank {rank}] all-reduce {which} done", file=sys.stderr, flush=True)
                     return 0
                 except Exception as e:      # noqa: BLE001  surfaced below; a C caller only sees the status
                     err.append(e)

@@ -2,6 +2,10 @@
 # Rehearsal of bench.py's N > 1 path on a one-GPU box: `python bench.py --gpus 2` starts its own two ranks
 # (torch.distributed.run), both on cuda:0 over gloo (SERL_AMD_BENCH_REHEARSAL=1).  gloo moves the 21 MB gradient through
 # the host with both ranks time-slicing one GPU, so the default rehearsal is a short one: REH_ARGS="--batch 32 --utd 2".
+# gloo stages device tensors through the host; with the update's kernels still queued the collective stalled for minutes
+# now and then, so serl_amd.dist waits for the device before a gloo all-reduce of a device tensor (2 s per rehearsal, 4 of 4).
+# REH_DUMP_AFTER=<s>: every rank dumps its Python stacks and exits after <s> seconds; SERL_AMD_DP_TRACE=1: a line around
+# every all-reduce.
 # PYTHONFAULTHANDLER + `timeout -s ABRT`: a hang ends with the Python stacks of all threads of every rank on stderr.
 export SERL_AMD_BENCH_REHEARSAL=1 PYTHONFAULTHANDLER=1
 mkdir -p gpurun_out/reh
