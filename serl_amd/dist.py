@@ -21,11 +21,14 @@ class DataParallel:
     def all_reduce_sum(self, tensor):
         if self.world_size > 1:
             if tensor.is_cuda and self._td.get_backend(self.group) == "gloo":
-                # gloo stages a device tensor through the host.  With the update's kernels still queued behind it the
-                # collective stalled for minutes, now and then (two ranks on one GPU, tools/rehearse_dp.sh); with the
-                # device idle it takes milliseconds.  RCCL ("nccl") enqueues on the stream and needs no such wait.
-                import torch
-                torch.cuda.synchronize(tensor.device)
+                # gloo has no device path of its own: torch stages a device tensor through pinned memory on pool streams.
+                # Two ranks on one GPU (tools/rehearse_dp.sh) stalled in that staging for minutes now and then -- with the
+                # update's kernels queued behind it, and at full size even with the device idle -- so the host copy is made
+                # here, on the caller's stream, and gloo only ever sees host memory.  RCCL ("nccl") is not affected.
+                host = tensor.cpu()
+                self._td.all_reduce(host, op=self._td.ReduceOp.SUM, group=self.group)
+                tensor.copy_(host)
+                return tensor
             self._td.all_reduce(tensor, op=self._td.ReduceOp.SUM, group=self.group)
         return tensor
 
