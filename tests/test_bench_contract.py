@@ -29,3 +29,20 @@ def test_bench_json_contract(dev):
         assert k in r, k
     assert r["bound"] in ("hbm", "mfma") and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert r["traffic"] is None or r["traffic"] >= 0.9 * r["algorithmic_bytes_per_launch"]
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_rehearsal(dev):
+    """`python bench.py --gpus 2` starts its own ranks (the command the driver runs for the scaling bench).  On a one-GPU
+    box both ranks share cuda:0 over gloo (SERL_AMD_BENCH_REHEARSAL=1, tools/rehearse_dp.sh); a short workload.  Checks
+    the launch path, the all-reduce hooks of the native driver and the aggregate value of the JSON line."""
+    env = dict(os.environ, SERL_AMD_BENCH_REHEARSAL="1", REH_DUMP_AFTER="150", MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--batch", "32", "--utd", "2"], capture_output=True, text=True, timeout=250, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    # 2 grad-steps per update on each of 2 ranks of 32 rows, normalised to 256-row batches
+    assert abs(d["value"] - 2 * 2 * 1000.0 / d["ms_per_step"] * (32 / 256.0)) <= 1e-2 * d["value"]
