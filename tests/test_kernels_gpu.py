@@ -230,7 +230,11 @@ def test_convs_fwd_dgrad_wgrad(dev, case):
 
 @pytest.mark.parametrize("case", [(3, 63, 63, 32, 64), (2, 64, 63, 32, 64), (3, 31, 31, 64, 128), (2, 29, 32, 64, 128),
                                   (1, 9, 11, 32, 64), (6, 15, 15, 128, 256), (1, 16, 13, 128, 256), (1, 7, 7, 64, 136),
-                                  (40, 31, 31, 64, 128), (30, 13, 9, 64, 128)])
+                                  (40, 31, 31, 64, 128), (30, 13, 9, 64, 128),
+                                  # C=32 -> 64 with >= 4 items per persistent block (85 blocks per group): the double-
+                                  # buffered patch, the counted vmcnt waits with the previous item's stores in flight and
+                                  # the weight gradient's accumulators kept over items (pconv.h) past the first item
+                                  (40, 63, 63, 32, 64), (33, 64, 63, 32, 64), (64, 63, 63, 32, 64)])
 def test_patch_conv_bit_identical_to_im2col(dev, case):
     """The LDS-patch kernels (csrc/pconv.h) and the LDS-DMA ring GEMM (csrc/sgemm_ring.h, layers with F >= 128) keep the
     k order and the MFMA sequence of the im2col kernels: outputs, ReLU byte masks and data gradients must be
@@ -638,6 +642,32 @@ def test_augmentations_module_bit_exact(dev):
     one = random_crop(key, imgs[0], 4)
     off = prng.randint(key, (2,), 0, 9)
     assert np.array_equal(one.cpu().numpy(), ol.random_crop_batch(imgs[:1], off[None])[0])
+
+
+def test_normal_stream_matches_jax_documentation(dev):
+    """The eps output of serl_tanh_gaussian_fwd (threefry -> uniform -> erf_inv on the GPU; the stream behind
+    serl/distributions/tanh_normal.py:53 as sampled at sac_learner.py:126,169) on the values the public JAX documentation
+    prints for jax.random.normal (tests/golden/prng_kat.json: jax_documentation).  1 ulp-level tolerance: the device
+    log1p / sqrt are not the host's."""
+    import json
+    import os
+    from serl_amd import prng as nprng
+    ops = _ops()
+    st = ops.current_stream()
+    d = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "prng_kat.json")))["jax_documentation"]
+    k42 = nprng.PRNGKey(42)
+    for key, B, A, want in ((nprng.PRNGKey(0), 2, 5, d["normal_prngkey0_10"]),
+                            (nprng.PRNGKey(0), 10, 1, d["normal_prngkey0_10"]),
+                            (k42, 1, 1, [d["normal_prngkey42_scalar"]]),
+                            (nprng.split(k42)[1], 1, 1, [d["normal_subkey_of_split_prngkey42_scalar"]])):
+        ms = torch.zeros((B, 2 * A), device=dev)
+        act = torch.zeros((B, A), device=dev); ep = torch.full((B, A), float("nan"), device=dev)
+        ops.tanh_gaussian_fwd(ms.data_ptr(), ms.data_ptr() + 4 * A, 2 * A, act.data_ptr(), A, None, ep.data_ptr(), None,
+                              B, A, key, 0, B, False, st)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(ep.cpu().numpy().reshape(-1), np.asarray(want, np.float32), rtol=3e-7, atol=0)
+        # mean 0, log-std 0: the action is tanh(eps)
+        np.testing.assert_allclose(act.cpu().numpy().reshape(-1), np.tanh(np.asarray(want, np.float64)), rtol=2e-6)
 
 
 def test_tanh_gaussian(dev):

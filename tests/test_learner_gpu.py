@@ -694,3 +694,109 @@ def test_fused_ensemble_forward_bit_identical(dev, kind, monkeypatch):
     for name in ("actor", "critic", "target_critic"):
         assert torch.equal(getattr(out["1"][0], name).store.flat, getattr(out["0"][0], name).store.flat), name
     assert out["1"][1] == out["0"][1]
+
+
+def test_full_size_patch_vs_im2col_update(dev):
+    """The headline shapes (2 x 128^2 cameras, stack 3, E1 encoder, batch 256, 10/2 critics) through update() with the
+    LDS-patch kernels (default) and with the im2col kernels they replace (serl_convs_set_patch_kernels(0)), from the same
+    agent and batch: at this size every persistent patch block walks many items.  The patch forward / data-gradient
+    kernels are bit-identical to im2col and the patch weight gradient of conv2 only sums its pixels in another order, so
+    after ONE critic step every gradient leaf except the second conv layer's kernel / bias must hold the same bits and
+    those two must agree to the weight gradient's 2e-5 summation tolerance; after a two-step call the logged scalars
+    agree to 1e-5 (Adam's sign-like first step may move a weight whose gradient is summation noise by 2 lr: parameters
+    are bounded like everywhere else in this file)."""
+    from serl_amd import ops
+    from serl_amd.agents import DrQLearner
+    keys = ("wrist_1", "wrist_2")
+    H = W = 128; S = 3; B = 256
+    obs_space, act_space = pixel_spaces(keys, H, W, S, 19, 7)
+    agent = DrQLearner.create(21, obs_space, act_space, pixel_keys=keys, cnn_features=(32, 64, 128, 256),
+                              cnn_filters=(3, 3, 3, 3), cnn_strides=(2, 2, 2, 2), latent_dim=64, num_qs=10,
+                              num_min_qs=2, critic_layer_norm=True, backup_entropy=False, init_temperature=0.1)
+    rng = np.random.default_rng(2)
+    batch2 = make_pixel_batch(rng, B * 2, keys, H, W, S, 19, 7, packed=True)
+    batch1 = {k: ({kk: vv[:B] for kk, vv in v.items()} if isinstance(v, dict) else v[:B]) for k, v in batch2.items()}
+    res = {}
+    try:
+        for mode in (1, 0):
+            ops.convs_set_patch_kernels(mode)
+            a1, i1 = agent.update(batch1, 1, pixel_keys=keys)
+            i1 = dict(i1)
+            torch.cuda.synchronize()
+            grads = {n: agent._shared[n].numpy_tree() for n in ("critic_grads", "actor_grads")}
+            a2, i2 = agent.update(batch2, 2, pixel_keys=keys)
+            res[mode] = (grads, i1, dict(i2), {n: getattr(a2, n).store.numpy_tree() for n in ("actor", "critic", "target_critic")})
+    finally:
+        ops.convs_set_patch_kernels(1)
+    from helpers import _leaves
+    g1, g0 = dict(_leaves(res[1][0]["critic_grads"])), dict(_leaves(res[0][0]["critic_grads"]))
+    assert set(g1) == set(g0)
+    nsummed = 0
+    for path in g0:
+        a, b = g1[path], g0[path]
+        if path[-2] in ("Conv_1", "Conv_5"):          # second conv layer of camera 1 / camera 2 (two_d4pg_encoder.py:30-38)
+            nsummed += 1
+            assert np.abs(a - b).max() <= 2e-5 * max(float(np.abs(b).max()), 1e-12), f"{'/'.join(path)}"
+        else:
+            assert np.array_equal(a, b), f"gradient leaf {'/'.join(path)} differs between patch and im2col kernels"
+    assert nsummed == 4
+    assert_tree_close(res[1][0]["actor_grads"], res[0][0]["actor_grads"], rtol=0, atol=0, what="actor grads")
+    for k in res[0][1]:
+        for which in (1, 2):
+            a, b = float(res[1][which][k]), float(res[0][which][k])
+            assert abs(a - b) <= 1e-5 * max(abs(b), 1e-2), f"info {k} (call {which}): {a} vs {b}"
+    for n in ("actor", "critic", "target_critic"):
+        assert_tree_close(res[1][3][n], res[0][3][n], atol=2.5 * 3e-4 * 2, mean_atol=2e-6, what=f"{n} params")
+
+
+def test_config2_utd20_two_buffers_matches_oracle(dev, prec):
+    """BASELINE config 2 at its real UTD: state RLPD (10/2 LayerNorm critics, no entropy backup), batch 256, UTD 20, every
+    256-row minibatch half online / half demo rows drawn from two `ReplayBuffer`s (serl/data/replay_buffer.py:44-79,
+    dataset.py:81-104), against the oracle fed by the oracle's own ring buffers with the same seeds
+    (sac_learner.py:221-238).  The sampled rows must be identical; logged scalars rel 1e-3 ("highest") / 5e-3
+    ("bf16_3x", 20 Adam steps per call from a re-synchronised state); rng chains equal."""
+    from oracle import learner as ol
+    from oracle import replay as orp
+    from serl_amd.agents import SACLearner
+    from serl_amd.data import ReplayBuffer
+    obs_space, act_space = state_spaces(17, 6)
+    B, U = 256, 20
+    half = B // 2
+    rng = np.random.default_rng(9)
+    bufs = {"online": ReplayBuffer(obs_space, act_space, 3000), "demo": ReplayBuffer(obs_space, act_space, 1000)}
+    obufs = {k: orp.new_ring(((17,), np.float32), ((6,), np.float32), cap) for k, cap in (("online", 3000), ("demo", 1000))}
+    for name, n in (("online", 3500), ("demo", 700)):              # the online ring has wrapped, the demo one is part-filled
+        for _ in range(n):
+            tr = dict(observations=rng.standard_normal(17).astype(np.float32),
+                      next_observations=rng.standard_normal(17).astype(np.float32),
+                      actions=rng.uniform(-1, 1, 6).astype(np.float32), rewards=np.float32(rng.standard_normal()),
+                      masks=np.float32(rng.random() < 0.99), dones=False)
+            bufs[name].insert(tr)
+            orp.ring_insert(obufs[name], tr)
+    orngs = {}
+    for i, k in enumerate(bufs):
+        bufs[k].seed(100 + i)
+        orngs[k] = orp.make_rng(100 + i)
+
+    def mix(on, de):        # per minibatch: 128 online rows then 128 demo rows
+        out = {}
+        for k in ("observations", "next_observations", "actions", "rewards", "masks", "dones"):
+            a, b = np.asarray(on[k]), np.asarray(de[k])
+            out[k] = np.concatenate([np.concatenate([a[i * half:(i + 1) * half], b[i * half:(i + 1) * half]]) for i in range(U)])
+        return out
+    agent = SACLearner.create(42, obs_space, act_space, num_qs=10, num_min_qs=2, critic_layer_norm=True,
+                              backup_entropy=False, init_temperature=0.1)
+    ostate, ocfg = agent_to_oracle(agent)
+    for it in range(2):
+        batch = mix(bufs["online"].sample(half * U), bufs["demo"].sample(half * U))
+        obatch = mix(orp.ring_sample(obufs["online"], orngs["online"], half * U)[0],
+                     orp.ring_sample(obufs["demo"], orngs["demo"], half * U)[0])
+        for k in batch:
+            assert np.array_equal(batch[k], obatch[k]), f"sampled {k} differ from the oracle's buffers"
+        if prec != "highest":
+            ostate, _ = agent_to_oracle(agent)
+        ostate, oinfo = ol.sac_update(ostate, ocfg, obatch, U)
+        agent, info = agent.update(batch, U)
+        assert_info_close(info, oinfo, rtol=1e-3 if prec == "highest" else 5e-3)
+        assert np.array_equal(agent.rng, ostate["rng"])
+    _check_params(agent, ostate, 3e-4, 2 * U)

@@ -1,5 +1,6 @@
 """Pins the oracle's (and the product's native) JAX random streams on the public known-answer vectors
-(SURVEY.md 8c): Random123 Threefry-2x32-20 KATs and the JAX-documented split(PRNGKey(0))."""
+(SURVEY.md 8c): Random123 Threefry-2x32-20 KATs, the JAX-documented split(PRNGKey(0)) / split(PRNGKey(42)) and the
+normal / uniform values the JAX documentation prints."""
 import json
 import os
 
@@ -22,6 +23,23 @@ def test_split_matches_jax_documentation():
     assert prng.prng_key(0).tolist() == [0, 0]
     assert prng.prng_key(42).tolist() == [0, 42]
     assert prng.split(prng.prng_key(0)).tolist() == GOLD["split_prngkey0"]
+
+
+def test_jax_documentation_values():
+    """uniform / normal (uniform -> XLA erf_inv polynomial) and a second split pinned on values the public JAX
+    documentation prints (tests/golden/prng_kat.json: jax_documentation); float32 values compared as float32."""
+    d = GOLD["jax_documentation"]
+    k42 = prng.prng_key(42)
+    assert prng.split(k42).tolist() == d["split_prngkey42"]
+    assert prng.normal(k42, ()) == np.float32(d["normal_prngkey42_scalar"])
+    sub = prng.split(k42)[1]
+    assert prng.normal(sub, ()) == np.float32(d["normal_subkey_of_split_prngkey42_scalar"])
+    np.testing.assert_array_equal(prng.normal(prng.prng_key(0), (10,)), np.asarray(d["normal_prngkey0_10"], np.float32))
+    assert prng.uniform(prng.prng_key(0), ()) == np.float32(d["uniform_prngkey0_scalar"])
+    # the product's host-side key plumbing on the same anchor
+    from serl_amd import prng as nprng
+    assert nprng.split(nprng.PRNGKey(42)).tolist() == d["split_prngkey42"]
+    assert nprng.split(nprng.PRNGKey(0)).tolist() == GOLD["split_prngkey0"]
 
 
 def test_self_consistency_fixtures():

@@ -125,3 +125,73 @@ def test_vice_update_classifier(dev, layer_norm):
             assert_tree_close(got, ostate["vice"][k]["params"], atol=2.5 * 3e-4, mean_atol=2e-5, what=f"params {k}")
     finally:
         serl_amd.set_matmul_precision("bf16_3x")
+
+
+def test_config4_full_size_vice_update_properties(dev):
+    """BASELINE config 4 at FULL size: 2 x 128^2 cameras, stack 1, batch 256, UTD 20 (5120 rows per call), frozen
+    MobileNetV3 encoder, VICE rewards inside `VICELearner.update` (vice_learner.py:277-314 -> sac_learner.py:221-238).
+    The CPU oracle would need minutes, so size-independent properties (the pattern of
+    test_full_size_update_properties), which exercise the 256-image backbone chunking and the `features ready` hook at
+    5120 rows:
+      1. augmented uint8 rows bit-exact vs the oracle's crop with the `key, rng = split` key order of this learner;
+      2. the rewards the update used (logged as their mean, 'vice_rews') equal the logit of `vice_reward` evaluated by
+         the public method on the same augmented observations;
+      3. the same call twice is bit-identical in every parameter, moment and logged scalar;
+      4. rng chain: one split per camera in vice_reward, then 4 per critic step + 2 (aug keys are not written back);
+      5. everything finite, step counters advanced."""
+    from oracle import learner as ol
+    from oracle import prng as oprng
+    from serl_amd.agents import VICELearner
+    HH = WW = 128
+    B, U = 256, 20
+    n = B * U
+    obs_space, act_space = pixel_spaces(KEYS, HH, WW, 1, 19, 7)
+    agent = VICELearner.create(13, obs_space, act_space, pixel_keys=KEYS, encoder="mobilenet", vice_dropout_rate=0.1, **RLPD)
+    rng = np.random.default_rng(4)
+    batch = make_pixel_batch(rng, n, KEYS, HH, WW, 1, 19, 7, packed=True)
+    a1, i1 = agent.update(batch, U, pixel_keys=KEYS)
+    i1 = dict(i1)
+    # 1. augmentation, every 41st row
+    rows = np.arange(0, n, 41)
+    ws = a1._ws(B)
+    key, r = oprng.split(agent.rng)
+    aug_obs = {}
+    for side, sl in (("obs", slice(0, 1)), ("next", slice(1, 2))):
+        kk = key
+        for cam in KEYS:
+            kcam, kk = oprng.split(kk)
+            offs = ol.crop_offsets_fast(kcam, n)[rows]
+            want = ol.random_crop_batch(batch["observations"][cam][rows][..., sl], offs)
+            full = ws.tensor(f"aug_{side}_{cam}", (n, HH, WW, 3), torch.uint8)
+            got = full[torch.as_tensor(rows, device=dev)]
+            assert np.array_equal(got.cpu().numpy().reshape(len(rows), HH, WW, 3, 1), want), f"aug {side} {cam}"
+            if side == "obs":
+                aug_obs[cam] = full.cpu().numpy().reshape(n, HH, WW, 3, 1)
+        key, r = oprng.split(r)
+    # 2. rewards of the update == public vice_reward on the augmented observations
+    _, rews = agent.vice_reward(aug_obs, KEYS)
+    m = rews["mean"].double().cpu().numpy()
+    want_mean = float(np.log(m / (1 - m)).mean())
+    assert abs(i1["vice_rews"] - want_mean) <= 1e-4 * max(abs(want_mean), 1e-2), (i1["vice_rews"], want_mean)
+    # 3. bit-identical repeat
+    a2, i2 = agent.update(batch, U, pixel_keys=KEYS)
+    assert i1 == dict(i2), (i1, dict(i2))
+    for name in ("actor", "critic", "target_critic"):
+        t1, t2 = getattr(a1, name), getattr(a2, name)
+        assert torch.equal(t1.store.flat, t2.store.flat), f"{name} parameters differ between two identical calls"
+        if name != "target_critic":
+            assert torch.equal(t1.mu, t2.mu) and torch.equal(t1.nu, t2.nu), f"{name} Adam moments differ"
+    assert torch.equal(a1.temp.buf, a2.temp.buf)
+    # 4. rng chain
+    e = agent.rng
+    for _ in KEYS:
+        _, e = oprng.split(e)
+    for _ in range(4 * U + 2):
+        _, e = oprng.split(e)
+    assert np.array_equal(a1.rng, e)
+    # 5.
+    assert all(np.isfinite(v) for v in i1.values())
+    assert bool(torch.isfinite(a1.critic.store.flat).all()) and bool(torch.isfinite(a1.actor.store.flat).all())
+    assert int(a1.critic.step) == int(agent.critic.step) + U and int(a1.actor.step) == int(agent.actor.step) + 1
+    for k in KEYS:
+        assert a1.vice_classifiers[k] is agent.vice_classifiers[k]          # update() never trains the classifiers
