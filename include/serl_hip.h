@@ -8,7 +8,9 @@
  * Conventions: plain pointers and sizes only; all device pointers are caller-allocated; `stream` is a
  * hipStream_t; tensors are row-major float32 unless stated; images are NHWC, conv kernels HWIO (flax).
  * Return value: 0 ok, 1 invalid argument (-> ValueError), 2 HIP error (-> RuntimeError); the message is in
- * serl_last_error() (thread-local).  No entry point allocates device memory or synchronises.
+ * serl_last_error() (thread-local).  The kernel entry points neither allocate device memory nor synchronise; the
+ * exceptions are the step driver (serl_learner_*: the handle owns HIP streams, events and a lazily allocated activation
+ * workspace, see there) and the first call of an entry point on a device, which may query device attributes.
  */
 #ifndef SERL_HIP_H
 #define SERL_HIP_H
@@ -75,8 +77,9 @@ int serl_convs_fwd(int ngroups, const void* const* x, const void* const* wf, con
  * two_d4pg_encoder.py:30-38). */
 int serl_convs_set_patch_kernels(int enable);
 /* Persistent patch kernels launched after this call spread over at most `cus` compute units (0: all).  The step driver
- * brackets the actor's run-ahead pass with it (SERL_AMD_ACTOR_CUS).  Process-wide, not synchronised; no counterpart in
- * the reference. */
+ * brackets the actor's run-ahead pass with it (SERL_AMD_ACTOR_CUS).  Per calling thread (thread-local: a thread that
+ * acts while another one learns is not affected); the weight gradient's grid -- its summation order -- ignores it.  No
+ * counterpart in the reference. */
 int serl_convs_set_cu_limit(int cus);
 /* Layers 1 + 2 of a NO-GRADIENT encoder pass (target critic, actor: two_d4pg_encoder.py:30-38 under stop_gradient /
  * in the target network) in one launch: uint8 frames [B][IH1][IW1][C1] -> 3x3 stride-2 conv (-> F1 = 32) + bias + ReLU ->
@@ -97,8 +100,11 @@ int serl_convs_wgrad(int ngroups, const void* const* x, const void* const* dz, f
  * callers that cannot call hipMalloc -- code under HIP graph capture, tight serving loops, harnesses that forbid it.
  * The split-K slabs live in a 64 MiB file-scope device array of the library (one copy per GPU, held until the process
  * ends); shapes whose slabs need more (serl_conv2d_wgrad_workspace_bytes > serl_convs_wgrad_noalloc_max_bytes) are
- * rejected with status 1.  Results are bit-identical to serl_convs_wgrad.  All calls on one GPU share the array: calls
- * that overlap in time on one GPU (different streams or threads) race. */
+ * rejected with status 1.  Results are bit-identical to serl_convs_wgrad (the slab count, i.e. the summation order,
+ * depends on the geometry and the device only, never on the size of a workspace).  All calls on one GPU share the
+ * array: calls that overlap in time on one GPU (different streams or threads) race.  The first call on a device looks
+ * up the array's address (hipGetSymbolAddress) and sets kernel attributes: make one warm-up call per device OUTSIDE
+ * any stream capture. */
 long long serl_convs_wgrad_noalloc_max_bytes(void);
 int serl_convs_wgrad_noalloc(int ngroups, const void* const* x, const void* const* dz, float* const* dw,
                              float* const* dbias, int in_u8, int B, int IH, int IW, int C, int KH, int KW, int stride,

@@ -126,25 +126,27 @@ class PixelBCLearner(Agent):
         keep = [state, actions]
         ub.state, ub.next_state, ub.actions = state.data_ptr(), state.data_ptr(), actions.data_ptr()
         # only the observations are read: a packed (S + 1)-frame leaf is addressed as its first S frames (`_unpack`)
-        lazy = DrQLearner._pixel_sources(self, batch, n, ub, keep)
-        actor = self.actor.clone()
-        bb = BcBuffers()
-        bb.actor, bb.actor_mu, bb.actor_nu = actor.store.base, actor.mu.data_ptr(), actor.nu.data_ptr()
-        bb.actor_grads, bb.actor_step = self._shared["actor_grads"].base, actor.step
-        fields = dict(actor=actor, rng=new_rng)
-        if self._HYBRID:
-            disc = self.discrete_actor.clone()
-            bb.disc, bb.disc_mu, bb.disc_nu = disc.store.base, disc.mu.data_ptr(), disc.nu.data_ptr()
-            bb.disc_grads, bb.disc_step = self._shared["disc_grads"].base, disc.step
-            fields["discrete_actor"] = disc
-        info = torch.zeros(2, dtype=f32, device=dev)
-        with torch.cuda.device(dev):
-            self._shared["native"].bc_update(bb, ub, ld, key_aug, key1, key2, info.data_ptr(), ops.current_stream())
-        actor.step += 1
-        if self._HYBRID:
-            fields["discrete_actor"].step += 1
-        for fw in lazy:
-            fw.consumed = True
+        from ...data.device_batch import hold_windows
+        with hold_windows(batch["observations"].values()):      # vs. insert() on a replay thread (device_batch.py)
+            lazy = DrQLearner._pixel_sources(self, batch, n, ub, keep)
+            actor = self.actor.clone()
+            bb = BcBuffers()
+            bb.actor, bb.actor_mu, bb.actor_nu = actor.store.base, actor.mu.data_ptr(), actor.nu.data_ptr()
+            bb.actor_grads, bb.actor_step = self._shared["actor_grads"].base, actor.step
+            fields = dict(actor=actor, rng=new_rng)
+            if self._HYBRID:
+                disc = self.discrete_actor.clone()
+                bb.disc, bb.disc_mu, bb.disc_nu = disc.store.base, disc.mu.data_ptr(), disc.nu.data_ptr()
+                bb.disc_grads, bb.disc_step = self._shared["disc_grads"].base, disc.step
+                fields["discrete_actor"] = disc
+            info = torch.zeros(2, dtype=f32, device=dev)
+            with torch.cuda.device(dev):
+                self._shared["native"].bc_update(bb, ub, ld, key_aug, key1, key2, info.data_ptr(), ops.current_stream())
+            actor.step += 1
+            if self._HYBRID:
+                fields["discrete_actor"].step += 1
+            for fw in lazy:
+                fw.consumed = True
         del keep
         return self.replace(**fields), BcInfo(info, n, self._INFO_KEYS)
 

@@ -17,7 +17,7 @@ from typing import Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-from ...data.device_batch import FrameWindows
+from ...data.device_batch import FrameWindows, hold_windows
 from ...native import KIND_FRAMES, KIND_PACKED, KIND_UNPACKED, UpdateBatch
 from ...networks.spec import NetConfig
 from ...spaces import is_dict
@@ -143,8 +143,9 @@ class DrQLearner(SACLearner):
         keep = [_to_dev(batch["observations"]["state"], dev, f32).reshape(n, cfg.state_dim),
                 _to_dev(batch["next_observations"]["state"], dev, f32).reshape(n, cfg.state_dim)]
         ub.state, ub.next_state = keep[0].data_ptr(), keep[1].data_ptr()
-        lazy = self._pixel_sources(batch, n, ub, keep)
-        out = self._run_update(batch, ub, n, utd_ratio, actor, self.rng, keep)
-        for fw in lazy:     # every row's gather is enqueued: later inserts are ordered behind it by the stream
-            fw.consumed = True
+        with hold_windows(batch["observations"].values()):      # vs. insert() on a replay thread (device_batch.py)
+            lazy = self._pixel_sources(batch, n, ub, keep)
+            out = self._run_update(batch, ub, n, utd_ratio, actor, self.rng, keep)
+            for fw in lazy:     # every row's gather is enqueued: later inserts (same stream) are ordered behind it
+                fw.consumed = True
         return out

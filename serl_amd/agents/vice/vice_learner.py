@@ -130,27 +130,29 @@ class VICELearner(DrQClassifierRewardLearner):
         keep = [_to_dev(batch["observations"]["state"], dev, f32).reshape(n, cfg.state_dim),
                 _to_dev(batch["next_observations"]["state"], dev, f32).reshape(n, cfg.state_dim)]
         ub.state, ub.next_state = keep[0].data_ptr(), keep[1].data_ptr()
-        lazy = self._pixel_sources(batch, n, ub, keep)
-        # new_agent.vice_reward(observations) runs on the agent's ORIGINAL rng (the augmentation splits are not written
-        # back) and advances it by one split per camera; SACLearner.update continues from there (:298-310)
-        rng_sac = self.rng
-        for _ in pixel_keys:
-            _, rng_sac = prng.split(rng_sac)
-        ub.use_sac_rng, ub.sac_rng[0], ub.sac_rng[1] = 1, int(rng_sac[0]), int(rng_sac[1])
-        rewards = torch.empty(n, dtype=f32, device=dev)                        # the batch's rewards are replaced (:304-308)
-        rew_sum = torch.zeros(1, dtype=f32, device=dev)
-        native = self._native
+        from ...data.device_batch import hold_windows
+        with hold_windows(batch["observations"].values()):      # released once the gather is enqueued (drq_learner.py)
+            lazy = self._pixel_sources(batch, n, ub, keep)
+            # new_agent.vice_reward(observations) runs on the agent's ORIGINAL rng (the augmentation splits are not
+            # written back) and advances it by one split per camera; SACLearner.update continues from there (:298-310)
+            rng_sac = self.rng
+            for _ in pixel_keys:
+                _, rng_sac = prng.split(rng_sac)
+            ub.use_sac_rng, ub.sac_rng[0], ub.sac_rng[1] = 1, int(rng_sac[0]), int(rng_sac[1])
+            rewards = torch.empty(n, dtype=f32, device=dev)                    # the batch's rewards are replaced (:304-308)
+            rew_sum = torch.zeros(1, dtype=f32, device=dev)
+            native = self._native
 
-        def vice_rewards_ready():
-            st = ops.current_stream()
-            feats = {k: native.buffer_ptr(B, f"bb_0_{cfg.cams.index(k)}")[0] for k in pixel_keys}   # augmented obs
-            logits = self._vice_logits(feats, n, st, tag="u")
-            ops.vice_reward([t.data_ptr() for t in logits], None, None, rewards.data_ptr(), n, st)
-            ops.colsum(rewards.data_ptr(), rew_sum.data_ptr(), 1, n, 1, 1, 0, st)
-        out = self._run_update(dict(batch, rewards=rewards), ub, n, utd_ratio, actor, self.rng, keep,
-                               features_hook=vice_rewards_ready, extra_info={"vice_rews": (rew_sum, 1.0 / n)})
-        for fw in lazy:
-            fw.consumed = True
+            def vice_rewards_ready():
+                st = ops.current_stream()
+                feats = {k: native.buffer_ptr(B, f"bb_0_{cfg.cams.index(k)}")[0] for k in pixel_keys}   # augmented obs
+                logits = self._vice_logits(feats, n, st, tag="u")
+                ops.vice_reward([t.data_ptr() for t in logits], None, None, rewards.data_ptr(), n, st)
+                ops.colsum(rewards.data_ptr(), rew_sum.data_ptr(), 1, n, 1, 1, 0, st)
+            out = self._run_update(dict(batch, rewards=rewards), ub, n, utd_ratio, actor, self.rng, keep,
+                                   features_hook=vice_rewards_ready, extra_info={"vice_rews": (rew_sum, 1.0 / n)})
+            for fw in lazy:
+                fw.consumed = True
         return out
 
     # ------------------------------------------------------------------ classifier training

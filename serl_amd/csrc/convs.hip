@@ -594,7 +594,8 @@ extern "C" int serl_convs_set_patch_kernels(int enable) {
 
 // Persistent patch kernels launched after this call spread over at most `cus` CUs (0: all).  The driver brackets the
 // actor's run-ahead pass with it: its persistent blocks otherwise hold every CU for ~100 us at a time, and the short
-// kernels of the critic step's latency-bound chain wait for one to retire.  Process-wide, not synchronised.
+// kernels of the critic step's latency-bound chain wait for one to retire.  Per calling thread (an acting thread that
+// launches patch kernels concurrently keeps its own, unset, limit); the weight gradient's grid ignores it.
 extern "C" int serl_convs_set_cu_limit(int cus) {
   g_pconv_cu_limit = cus > 0 ? cus : 0;
   return SERL_OK;
@@ -775,7 +776,7 @@ static int convs_wgrad_impl(const char* name, int ngroups, const void* const* x,
     a.d_bands = make_fastdiv(a.nbands);
     for (int i = 0; i < ngroups; ++i) { a.x[i] = (const ushort_t*)x[i]; a.dz[i] = (const ushort_t*)dz[i]; }
     int nslab = 0;
-    if (int e = pconv_wgrad_launch(a, ngroups, workspace_bytes, &nslab, (hipStream_t)stream, name)) return e;
+    if (int e = pconv_wgrad_launch(a, ngroups, nsplit, workspace_bytes, &nslab, (hipStream_t)stream, name)) return e;
     if (nslab > 0) {
       ReduceArgs ra; ra.slab = workspace; ra.nsplit = nslab; ra.kkc = kkc; ra.F = F;
       for (int i = 0; i < ngroups; ++i) { ra.dw[i] = dw[i]; ra.db[i] = dbias[i]; }

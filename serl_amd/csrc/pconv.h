@@ -62,7 +62,7 @@ struct PFwdCfg {
 };
 
 // CUs a persistent grid spreads over (all of them; SERL_PCONV_CUS caps it for experiments with co-running streams)
-static int g_pconv_cu_limit = 0;        // serl_convs_set_cu_limit: a caller-set cap for the launches that follow (0: none)
+static thread_local int g_pconv_cu_limit = 0;   // serl_convs_set_cu_limit: the calling THREAD's cap for the launches that follow (0: none)
 static int pconv_cus(int ncu) {
   static int cap = -1;
   if (cap < 0) { const char* e = getenv("SERL_PCONV_CUS"); cap = e ? atoi(e) : 0; }
@@ -1959,9 +1959,13 @@ __global__ __launch_bounds__(640, 1) void pconv_wgrad_kernel(const PConvWgradArg
   }
 }
 
-// returns the number of slabs per group through *nslab (0: the workspace cannot hold even one block's slabs)
-static int pconv_wgrad_launch(PConvWgradArgs& a, int ngroups, long long workspace_bytes, int* nslab, hipStream_t st,
-                              const char* name) {
+// returns the number of slabs per group through *nslab (0: the workspace cannot hold the slabs).  The slab count fixes the
+// summation order, so it depends on the geometry and the device only -- the CU count, the split count `max_slabs` of
+// wgrad_plan (what serl_conv2d_wgrad_workspace_bytes sizes a workspace for) and the item count -- never on how large the
+// caller's workspace happens to be or on serl_convs_set_cu_limit: serl_convs_wgrad and serl_convs_wgrad_noalloc give the
+// same bits.  workspace_bytes is a sufficiency check only.
+static int pconv_wgrad_launch(PConvWgradArgs& a, int ngroups, int max_slabs, long long workspace_bytes, int* nslab,
+                              hipStream_t st, const char* name) {
   static bool opted[64] = {};
   static int ncu[64] = {};
   int dev = 0;
@@ -1975,14 +1979,14 @@ static int pconv_wgrad_launch(PConvWgradArgs& a, int ngroups, long long workspac
   const int nitems = a.B * a.nbands;
   static int cap = -1;                    // SERL_PCONV_WG_CUS: CUs this kernel spreads over (experiments with co-running streams)
   if (cap < 0) { const char* e = getenv("SERL_PCONV_WG_CUS"); cap = e ? atoi(e) : 0; }
-  const int cus = pconv_cus(ncu[dev]);
+  const int cus = ncu[dev] > 0 ? ncu[dev] : 256;
   int gx = (cap > 0 && cap < cus ? cap : cus) / ngroups;
-  const long long fit = workspace_bytes / ((long long)ngroups * PWgradCfg::SLAB * 4);
-  if (gx > fit) gx = (int)fit;
+  if (gx > max_slabs) gx = max_slabs;
   if (gx > nitems) gx = nitems;
   if (gx < 1) { *nslab = 0; return SERL_OK; }
   const int per = cdiv(nitems, gx);
   gx = cdiv(nitems, per);                    // every block has at least one item
+  if ((long long)ngroups * gx * PWgradCfg::SLAB * 4 > workspace_bytes) { *nslab = 0; return SERL_OK; }
   *nslab = gx;
   hipLaunchKernelGGL(pconv_wgrad_kernel, dim3(gx, 1, ngroups), dim3(PWgradCfg::NT), PWgradCfg::LDS, st, a);
   SERL_CHECK_LAUNCH(name);

@@ -8,8 +8,11 @@ class FrameWindows:
     fuses the gather with `_unpack` and the random-shift crop in one kernel; `materialize()` returns
     the packed (n,H,W,3,S+1) uint8 tensor the reference would have produced."""
 
-    def __init__(self, frames, capacity, indx, num_stack, first_rows=None):
+    def __init__(self, frames, capacity, indx, num_stack, first_rows=None, lock=None):
         self.frames, self.capacity, self.indx, self.num_stack = frames, int(capacity), indx, int(num_stack)
+        # the owning buffer's lock: insert() holds it while it pins batches and overwrites a row; the learner holds it
+        # from the moment it reads `packed` until the gather is enqueued and `consumed` is set (hold_windows below)
+        self.lock = lock
         # The reference gathers pixels at sample time, so its batches cannot change afterwards.  A lazy window batch
         # can: an insert() that lands on one of its rows before the learner has enqueued the gather would change it.
         # The owning buffer therefore keeps un-consumed batches registered and, before overwriting a row that one of
@@ -47,3 +50,22 @@ class FrameWindows:
         ops.gather_window(self.frames.data_ptr(), self.capacity, self.indx.data_ptr(), out.data_ptr(), n, H * W * C,
                           self.num_stack, ops.current_stream())
         return out
+
+
+def hold_windows(leaves):
+    """Context manager: the locks of the device replay buffers that own the lazy FrameWindows among `leaves`, held
+    together.  An update() enters it before it looks at `packed` and leaves it after the native call has enqueued the
+    gather: an insert() from another thread (the reference's replay thread + learner thread pattern) then either pins
+    the batch before the update reads it, or overwrites the row after the gather is in the stream.  Ordering on the
+    DEVICE is by stream: insert() copies on torch's current stream and update() launches on torch's current stream, so
+    both threads must use the same stream (the default one unless the caller changes it)."""
+    import contextlib
+    stack = contextlib.ExitStack()
+    seen = []
+    for leaf in leaves:
+        lock = getattr(leaf, "lock", None) if isinstance(leaf, FrameWindows) else None
+        if lock is not None and all(lock is not l for l in seen):
+            seen.append(lock)
+    for lock in sorted(seen, key=id):           # a fixed order: two learners on two buffers cannot deadlock
+        stack.enter_context(lock)
+    return stack

@@ -48,6 +48,8 @@ class MemoryEfficientReplayBuffer(ReplayBuffer):
         super().__init__(Dict(host_spaces), action_space, capacity, next_observation_space=next_space)
         self._frames = None
         self._pending = []          # weak references to lazy window batches the learner has not gathered yet
+        import threading
+        self._lock = threading.RLock()      # insert (pin + overwrite) vs. update (read `packed` .. enqueue the gather)
         if self._device is not None:
             import torch
             self._frames = {k: torch.zeros((capacity, *self._frame_shape[k]), dtype=torch.uint8, device=self._device)
@@ -59,9 +61,10 @@ class MemoryEfficientReplayBuffer(ReplayBuffer):
         self._is_correct_index[at] = valid
         if self._frames is not None:
             import torch
-            self._protect_pending(at)
-            for k, f in frames.items():
-                self._frames[k][at].copy_(torch.from_numpy(np.ascontiguousarray(f)))
+            with self._lock:
+                self._protect_pending(at)
+                for k, f in frames.items():
+                    self._frames[k][at].copy_(torch.from_numpy(np.ascontiguousarray(f)))
         else:
             row = dict(row)
             row["observations"] = dict(row["observations"], **frames)
@@ -81,6 +84,13 @@ class MemoryEfficientReplayBuffer(ReplayBuffer):
             else:
                 live.append(ref)
         self._pending = live
+
+    def _prune_pending(self):
+        """Drop batches that are gone, gathered or pinned (a learner that samples without inserting -- offline training,
+        bench loops -- must not grow the list)."""
+        with self._lock:
+            self._pending = [r for r in self._pending
+                             if (fw := r()) is not None and not fw.consumed and fw.packed is None]
 
     def _row_at(self, idx):
         row = take(self.dataset_dict, idx)
@@ -176,8 +186,10 @@ class MemoryEfficientReplayBuffer(ReplayBuffer):
         S = self._num_stack
         first = indx.astype(np.int64) - S
         first[first < 0] += self._capacity - S                  # the negative-index wrap of the window view (C.7)
+        self._prune_pending()
         for k in self.pixel_keys:
-            fw = FrameWindows(self._frames[k], self._capacity, ix, S, first_rows=first)
-            self._pending.append(weakref.ref(fw))
+            fw = FrameWindows(self._frames[k], self._capacity, ix, S, first_rows=first, lock=self._lock)
+            with self._lock:
+                self._pending.append(weakref.ref(fw))
             out["observations"][k] = fw
         return freeze(out)

@@ -702,8 +702,8 @@ def test_full_size_patch_vs_im2col_update(dev):
     agent and batch: at this size every persistent patch block walks many items.  The patch forward / data-gradient
     kernels are bit-identical to im2col and the patch weight gradient of conv2 only sums its pixels in another order, so
     after ONE critic step every gradient leaf except the second conv layer's kernel / bias must hold the same bits and
-    those two must agree to the weight gradient's 2e-5 summation tolerance; after a two-step call the logged scalars
-    agree to 1e-5 (Adam's sign-like first step may move a weight whose gradient is summation noise by 2 lr: parameters
+    those two must agree to the weight gradient's 2e-5 summation tolerance; after the one-step call the logged scalars agree to 1e-5,
+    after a two-step call to 2e-4 (Adam's sign-like first step may move a weight whose gradient is summation noise by 2 lr: parameters
     are bounded like everywhere else in this file)."""
     from serl_amd import ops
     from serl_amd.agents import DrQLearner
@@ -740,11 +740,15 @@ def test_full_size_patch_vs_im2col_update(dev):
         else:
             assert np.array_equal(a, b), f"gradient leaf {'/'.join(path)} differs between patch and im2col kernels"
     assert nsummed == 4
-    assert_tree_close(res[1][0]["actor_grads"], res[0][0]["actor_grads"], rtol=0, atol=0, what="actor grads")
+    # the actor step runs on the critic AFTER its Adam step (sac_learner.py:235), i.e. behind conv2's re-ordered sums
+    assert_tree_close(res[1][0]["actor_grads"], res[0][0]["actor_grads"], rtol=1e-4, what="actor grads")
     for k in res[0][1]:
         for which in (1, 2):
             a, b = float(res[1][which][k]), float(res[0][which][k])
-            assert abs(a - b) <= 1e-5 * max(abs(b), 1e-2), f"info {k} (call {which}): {a} vs {b}"
+            # call 1: one critic step from identical parameters; call 2: behind Adam's first, sign-like steps, which
+            # turn conv2's re-ordered sums into +-lr differences of single weights (measured 4e-5 on actor_loss)
+            tol = 1e-5 if which == 1 else 2e-4
+            assert abs(a - b) <= tol * max(abs(b), 1e-2), f"info {k} (call {which}): {a} vs {b}"
     for n in ("actor", "critic", "target_critic"):
         assert_tree_close(res[1][3][n], res[0][3][n], atol=2.5 * 3e-4 * 2, mean_atol=2e-6, what=f"{n} params")
 

@@ -56,6 +56,11 @@ def test_wgrad_noalloc_matches_workspace_variant(dev):
     n2 = _case(dev, ops, rng, 1, 3, 15, 8, 16, False)
     assert n2 < n1 <= limit
     _case(dev, ops, rng, 2, 4, 128, 9, 32, True)          # uint8 first layer
+    # C = 32 -> F = 64 at IH = 63: the LDS-patch weight gradient (pconv_wgrad_kernel), whose slab count -- the summation
+    # order -- must come from the geometry alone, not from the size of the workspace (exact-need here, 64 MiB there)
+    _case(dev, ops, rng, 2, 16, 63, 32, 64, False)
+    _case(dev, ops, rng, 2, 64, 63, 32, 64, False)
+    _case(dev, ops, rng, 3, 5, 63, 32, 64, False)
     # beyond the array: rejected with a clear error, nothing launched
     big = ops.conv2d_wgrad_workspace_bytes(8, 64, 15, 15, 256, 3, 3, 2, 512)
     assert big > limit
