@@ -92,6 +92,123 @@ def cpu_baseline(seed=0, progress=lambda m: None):
                       "CPU restatement (torch-CPU fp32), not JAX/XLA"}
 
 
+def _timed_calls(torch, fn, n, warm=2):
+    """n calls of fn() between synchronisations after `warm` un-timed ones -> seconds per call."""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
+
+
+def extra_configs(progress):
+    """The other configurations north_star states its target on (BASELINE.json configs[1], [3], [4]), driver-visible as
+    extra keys of the JSON line; the headline `value` is untouched.  All at the library's default precision (bf16_3x),
+    synthetic data resident in HBM, same definition of a grad-step as the headline."""
+    import torch
+    from helpers import make_pixel_batch, make_state_batch, pixel_spaces, state_spaces
+    from serl_amd.agents import DrQLearner, SACLearner, VICELearner
+    from serl_amd.data import MemoryEfficientReplayBuffer
+    from serl_amd.data.replay_buffer import to_device
+    dev = torch.device("cuda")
+    out = {}
+    # ---- C2: state-based RLPD (obs 17, act 6, 10/2 LayerNorm critics, no entropy backup), batch 256, UTD 20
+    obs_space, act_space = state_spaces(17, 6)
+    agent = SACLearner.create(42, obs_space, act_space, num_qs=10, num_min_qs=2, critic_layer_norm=True,
+                              backup_entropy=False, init_temperature=0.1)
+    rng = np.random.default_rng(0)
+    sb = [to_device(make_state_batch(rng, 256 * 20, 17, 6), dev) for _ in range(4)]
+    st = {"a": agent, "i": 0}
+
+    def c2_call():
+        st["a"], _ = st["a"].update(sb[st["i"] % 4], 20)
+        st["i"] += 1
+    t = _timed_calls(torch, c2_call, 20, warm=3)
+    out["c2_us_per_grad_step"] = round(t / 20 * 1e6, 1)
+    out["c2_value"] = round(20 / t, 1)
+    out["c2_note"] = ("BASELINE config 2: state RLPD update(), batch 256, UTD 20, 10/2 LayerNorm critics; launch-latency "
+                      "bound (1.2 GFLOP, 26 MB per grad-step): us per grad-step is the figure of merit; 20 timed calls")
+    progress(f"c2: {out['c2_us_per_grad_step']} us per grad-step")
+    del agent, st, sb
+    # ---- C5 shape on one GPU: the headline learner at batch 4096, UTD 1
+    obs_space, act_space = pixel_spaces(KEYS, H, W, STACK, STATE_DIM, ACT_DIM)
+    agent = DrQLearner.create(42, obs_space, act_space, pixel_keys=KEYS, **AGENT_KW)
+    buf = MemoryEfficientReplayBuffer(obs_space, act_space, 3000, pixel_keys=KEYS, device="cuda")
+    fill_buffer(buf, 2000, seed=1)
+    buf.seed(1)
+    it = buf.get_iterator(queue_size=1, sample_args=dict(batch_size=4096, pack_obs_and_next_obs=True,
+                                                         demo_batch_size=2048, demo_size=500))
+    pb = [next(it) for _ in range(3)]
+    st = {"a": agent, "i": 0}
+
+    def c5_call():
+        st["a"], _ = st["a"].update(pb[st["i"] % 3], 1, pixel_keys=KEYS)
+        st["i"] += 1
+    t = _timed_calls(torch, c5_call, 6, warm=2)
+    out["c5_1gpu_value"] = round(1 / t * 4096 / 256, 1)
+    out["c5_1gpu_ms_per_update"] = round(t * 1e3, 2)
+    out["c5_note"] = ("BASELINE config 5 per-GPU shape on ONE GPU: DrQ-RLPD update(), batch 4096, UTD 1; value in 256-row "
+                      "grad-step equivalents per second (every update carries its own actor + temperature step); 6 timed calls")
+    progress(f"c5 (1 GPU, batch 4096, UTD 1): {out['c5_1gpu_value']} grad-step equivalents/s")
+    del agent, st, pb, it, buf
+    torch.cuda.empty_cache()
+    # ---- C4: frozen MobileNetV3 encoder + VICE rewards inside update(), stack 1, batch 256, UTD 20, and one
+    # update_classifier per 100 update() calls (binpick_franka_fwbw_vice.py:59,86-89)
+    obs_space, act_space = pixel_spaces(KEYS, H, W, 1, STATE_DIM, ACT_DIM)
+    kw = {k: v for k, v in AGENT_KW.items() if not k.startswith("cnn_")}
+    pool = {k: rng.integers(0, 256, size=(64, H, W, 3, 1), dtype=np.uint8) for k in KEYS}
+    agent = VICELearner.create(42, obs_space, act_space, pixel_keys=KEYS, encoder="mobilenet", vice_dropout_rate=0.1,
+                               vice_goal_pool=pool, **kw)
+    vb = [to_device(make_pixel_batch(rng, 256 * 20, KEYS, H, W, 1, STATE_DIM, ACT_DIM, packed=True), dev) for _ in range(2)]
+    cb = to_device(make_pixel_batch(rng, 256, KEYS, H, W, 1, STATE_DIM, ACT_DIM, packed=True), dev)
+    st = {"a": agent, "i": 0}
+
+    def c4_call():
+        st["a"], _ = st["a"].update(vb[st["i"] % 2], 20, pixel_keys=KEYS)
+        st["i"] += 1
+
+    def c4_clf():
+        st["a"], _ = st["a"].update_classifier(cb, KEYS)
+    t_upd = _timed_calls(torch, c4_call, 4, warm=2)
+    t_clf = _timed_calls(torch, c4_clf, 3, warm=1)
+    t = t_upd + t_clf / 100.0
+    out["c4_value"] = round(20 / t, 1)
+    out["c4_ms_per_update"] = round(t_upd * 1e3, 2)
+    out["c4_update_classifier_ms"] = round(t_clf * 1e3, 2)
+    # the frozen backbone is the dominant family of this config: its forward over the 4 x 5120 augmented images of a call
+    bb = agent._shared["backbone"]
+    imgs = torch.from_numpy(rng.integers(0, 256, size=(256, H, W, 3), dtype=np.uint8)).to(dev)
+    fo = torch.empty((256,) + tuple(bb.feature_shape(H, W)), dtype=torch.float32, device=dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    bb.forward(imgs, out=fo)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(5):
+        bb.forward(imgs, out=fo)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 5
+    flops = 2 * 72e6 * (H * W) / (128 * 128) * 256        # DESIGN.md 3: 72 MMAC per 128 x 128 image
+    byts = 7.0e6 * (H * W) / (128 * 128) * 256            # ~7 MB of fp32 NHWC activation traffic per image
+    ach = byts / (ms * 1e-3) / 1e9
+    out["c4_roofline"] = {"kernel": "frozen MobileNetV3-Large forward (stem + 15 blocks: depthwise / SE kernels + igemm "
+                                    "pointwise convs), 256 images per launch chain", "bound": "hbm", "achieved": round(ach, 1),
+                          "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4),
+                          "avg_chain_ms": round(ms, 3), "algorithmic_bytes": byts, "algorithmic_flops": flops,
+                          "tflops": round(flops / (ms * 1e-3) / 1e12, 2), "traffic": None,
+                          "share_of_update": round(ms * 4 * 20 / (t_upd * 1e3), 3),
+                          "timing": "torch events on the launch stream around 5 repeats of the 256-image chain, stand-alone"}
+    out["c4_note"] = ("BASELINE config 4: DrQ-RLPD with encoder='mobilenet' (frozen synthetic MobileNetV3-Large) + VICE rewards "
+                      "in update(), 2 cams 128x128x3, stack 1, batch 256, UTD 20; value = 20 / (update + update_classifier/100) "
+                      "grad-steps/s; 4 timed update() calls, 3 update_classifier calls")
+    progress(f"c4: {out['c4_value']} grad-steps/s ({out['c4_ms_per_update']} ms per update, classifier step "
+             f"{out['c4_update_classifier_ms']} ms)")
+    return out
+
+
 def spawn_ranks(n, argv):
     """`python bench.py --gpus N` without a launcher: start the N ranks as children (torch.distributed.run, rendezvous
     on 127.0.0.1) before this process imports torch or touches the GPU; relay rank 0's JSON line."""
@@ -132,6 +249,8 @@ def main():
                     help="rows per critic step over ALL ranks (BASELINE config 5: 4096 / 8192): every rank takes "
                          "global_batch / gpus rows (strong scaling); default: 256 rows per rank (weak scaling)")
     ap.add_argument("--no-highest", action="store_true", help="skip the extra timed steps at precision 'highest'")
+    ap.add_argument("--no-extra-configs", action="store_true",
+                    help="skip the c2 / c4 / c5 legs (state RLPD, MobileNet + VICE, batch 4096 on one GPU)")
     ap.add_argument("--phases", action="store_true",
                     help="after the timed region, one more update() with HIP-event marks between its phases (stderr)")
     ap.add_argument("--precision", default="bf16_3x", choices=["bf16_3x", "highest"],
@@ -210,19 +329,35 @@ def main():
     torch.cuda.synchronize()
     progress("warm-up done")
     native = agent._native
-    timer = None
-    if not args.no_kernel_timer:      # HIP events around every conv launch, recorded by the driver on the launch stream
-        timer = native
-        native.timing_reset()
-        native.set_timing(conv_events=True)
+    if dist is not None:
+        dist.timing_reset()
+        dist.timing = True
     barrier()
+    c0 = time.thread_time()
     t0 = time.perf_counter()
     for b in batches[args.warmup:]:
         agent, info = agent.update(b, UTD, pixel_keys=KEYS)
-    host_enqueue = time.perf_counter() - t0           # update() does not wait for the GPU: this is pure launch time
-    barrier()
+    host_enqueue = time.perf_counter() - t0           # update() does not wait for the GPU: this is pure launch time ...
+    host_cpu = time.thread_time() - c0                # ... of which this much is CPU time of the calling thread (the rest:
+    barrier()                                         # waiting on a full hardware queue)
     elapsed = time.perf_counter() - t0
-    native.set_timing(conv_events=False)
+    allreduce_s = None
+    if dist is not None:
+        dist.timing = False
+        allreduce_s = dist.allreduce_seconds
+    # roofline events: a second, short loop with HIP events around every conv launch (recorded by the driver on the
+    # launch stream) -- kept out of the timed region above (1 640 extra hipEventRecord calls per step)
+    timer = None
+    if not args.no_kernel_timer:
+        timer = native
+        native.timing_reset()
+        native.set_timing(conv_events=True)
+        ragent = agent
+        for b in batches[-min(2, len(batches)):]:
+            ragent, _ = ragent.update(b, UTD, pixel_keys=KEYS)
+        torch.cuda.synchronize()
+        native.set_timing(conv_events=False)
+        del ragent
     progress(f"timed region done: {elapsed / args.steps * 1e3:.2f} ms/step")
     # end to end: the same loop with the host-side index draw, rejection resampling and H2D of the small leaves inside
     # it (the iterator samples batch i+1 while the GPU runs update i: update() does not block the host)
@@ -248,11 +383,15 @@ def main():
         for k, v in acc.items():
             print(f"phase {k:28s} n={len(v):3d} mean {sum(v) / len(v) * 1e3:8.1f} us  total {sum(v):7.2f} ms",
                   file=sys.stderr)
-    if dist is not None:
+    def max_over_ranks(vals):
+        if dist is None:
+            return vals
         import torch.distributed as td
-        t = torch.tensor([elapsed, e2e], device="cuda", dtype=torch.float64)
+        # gloo (one-GPU rehearsal): a host tensor -- torch's staging of device tensors for gloo has stalled here (dist.py)
+        t = torch.tensor(vals, device="cpu" if rehearsal else "cuda", dtype=torch.float64)
         td.all_reduce(t, op=td.ReduceOp.MAX)
-        elapsed, e2e = float(t[0].item()), float(t[1].item())
+        return [float(x) for x in t.tolist()]
+    elapsed, e2e = max_over_ranks([elapsed, e2e])
 
     # the same steps at precision "highest" (exact fp32 MFMA: the precision at which north_star's free-running
     # rel-1e-3 tolerance holds), timed by this run so that the figure is not only the builder's
@@ -268,10 +407,7 @@ def main():
             agent_h, _ = agent_h.update(b, UTD, pixel_keys=KEYS)
         barrier()
         th = time.perf_counter() - t0
-        if dist is not None:
-            t = torch.tensor([th], device="cuda", dtype=torch.float64)
-            td.all_reduce(t, op=td.ReduceOp.MAX)
-            th = float(t.item())
+        th = max_over_ranks([th])[0]
         highest_value = len(hb) * UTD * world / th * (BATCH / 256.0)
         serl_amd.set_matmul_precision(precision)
         progress("precision 'highest' steps done")
@@ -355,6 +491,9 @@ def main():
         "highest_note": "the same update() calls at precision 'highest' (exact fp32 MFMA), 3 timed steps in this run",
         "host_index_sampling_ms_per_update": round(sample_ms, 2),
         "host_enqueue_ms_per_step": round(host_enqueue / args.steps * 1e3, 2),
+        "host_cpu_ms_per_step": round(host_cpu / args.steps * 1e3, 2),
+        "host_note": "enqueue = wall time of the update() calls (includes waiting on a full hardware queue); cpu = "
+                     "time.thread_time() of the calling thread over the same calls",
         "end_to_end_value": None if rehearsal else round(args.steps * UTD * world / e2e * (BATCH / 256.0), 3),
         "end_to_end_note": "same steps with buffer.sample (index draw + rejection + H2D of state/action leaves) inside "
                            "the loop; frames stay in HBM",
@@ -362,6 +501,18 @@ def main():
     }
     if roofline is not None:
         out["roofline"] = roofline
+    if rehearsal:
+        out["rehearsal"] = True        # ranks share ONE GPU over gloo: a launch-path check, not a scaling measurement
+        out["metric"] = "REHEARSAL (all ranks on one GPU, gloo) of: " + out["metric"]
+    if world > 1:
+        out["ranks_seen"] = world
+        # time inside the gradient all-reduces of the timed region (stream events around each RCCL call; host wall time
+        # under gloo), max over ranks: includes waiting for the slowest rank to arrive
+        out["allreduce_ms_per_step"] = round(max_over_ranks([allreduce_s])[0] / args.steps * 1e3, 3)
+    if rank == 0 and world == 1 and headline and not args.no_extra_configs:
+        del agent, batches, it, buf
+        torch.cuda.empty_cache()
+        out.update(extra_configs(progress))
     if rank == 0 and world == 1 and not args.no_cpu_baseline and headline:
         progress("CPU baseline (oracle on the host cores, ~60 s) ...")
         out["cpu_baseline"] = cpu_baseline(progress=progress)

@@ -304,6 +304,11 @@ typedef struct {
   int feat_h, feat_w, feat_c;  /* encoder 1: serl_mbv3_feature_shape(height, width) */
   float encoder_dropout;       /* encoder 1: Dropout rate behind the spatial embeddings in training passes (0.1) */
   int critic_no_action;        /* != 0: the "critic" slot is the hybrid BC learner's discrete actor: MLP on the latent only */
+  float critic_dropout;        /* critic_dropout_rate (sac_learner.py:47, mlp.py:26-29): nn.Dropout behind every hidden Dense of
+                                  the critic MLPs (before LayerNorm) in the training=True applies -- target critic, critic,
+                                  the actor step's critic; 0 = None.  Mask stream BUILD-DEFINED (flax folds the module path and
+                                  the vmap axis into the rng): bernoulli(fold_in(fold_in(key, layer), member position), keep)
+                                  over the (global minibatch, width) array, keyed by the global row */
 } serl_learner_config;
 /* flat fp32 device buffers of ONE agent copy (parameters, Adam moments, temperature state {log_temp, mu, nu}) plus the
  * gradient buffers (same layouts); update() steps them in place -- the caller clones first to keep the old agent valid */

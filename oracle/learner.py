@@ -76,27 +76,43 @@ def layer_norm(p, x):
     return (x - mean) * mul + p["bias"]
 
 
-def mlp(p, x, use_layer_norm, activate_final=True):
-    """serl/networks/mlp.py:18-35 (ReLU, no dropout: dropout_rate None in every config)."""
+def critic_dropout(x, key, layer, member, rate, shard=None):
+    """nn.Dropout(rate)(x, deterministic=False) behind hidden Dense `layer` of ensemble member position `member`
+    (serl/networks/mlp.py:26-29; the vmapped Ensemble splits the dropout rng per member, ensemble.py:11-16).  flax derives
+    the rng by folding in the module path and the vmap axis (not restatable without flax): BUILD-DEFINED as
+    fold_in(fold_in(key, layer), member) -- parity unpinned for the mask stream.  shard as in encoder_dropout."""
+    keep = np.float32(1.0 - rate)
+    B, Fd = x.shape
+    off, total = shard if shard is not None else (0, B)
+    mask = prng.bernoulli(prng.fold_in(prng.fold_in(key, layer), member), keep, (total, Fd))[off:off + B]
+    return torch.where(torch.as_tensor(mask), x / float(keep), torch.zeros_like(x))
+
+
+def mlp(p, x, use_layer_norm, activate_final=True, dropout=None):
+    """serl/networks/mlp.py:18-35 (ReLU).  dropout: None (dropout_rate None in every shipped config, or training=False)
+    or (key, member position, rate, shard): Dense -> Dropout -> [LayerNorm] -> ReLU."""
     n = len([k for k in p if k.startswith("Dense_")])
     for i in range(n):
         x = dense(p[f"Dense_{i}"], x)
         if i + 1 < n or activate_final:
+            if dropout is not None:
+                x = critic_dropout(x, dropout[0], i, dropout[1], dropout[2], dropout[3])
             if use_layer_norm:
                 x = layer_norm(p[f"LayerNorm_{i}"], x)
             x = torch.relu(x)
     return x
 
 
-def ensemble_q(p, obs, actions, use_layer_norm):
+def ensemble_q(p, obs, actions, use_layer_norm, dropout=None):
     """serl/networks/ensemble.py:8-22 + state_action_value.py:11-19.
-    Every leaf of p has a leading ensemble axis; returns (E, B)."""
+    Every leaf of p has a leading ensemble axis; returns (E, B).  dropout: None or (key, rate, shard)."""
     inp = torch.cat([obs, actions], -1)
     some = p["Dense_0"]["kernel"]
     qs = []
     for e in range(some.shape[0]):
         pe = tree_map(lambda a: a[e], p)
-        h = mlp(pe["MLP_0"], inp, use_layer_norm, True)
+        h = mlp(pe["MLP_0"], inp, use_layer_norm, True,
+                None if dropout is None else (dropout[0], e, dropout[1], dropout[2]))
         qs.append(dense(pe["Dense_0"], h).squeeze(-1))
     return torch.stack(qs, 0)
 
@@ -208,7 +224,9 @@ def critic_qs(p, obs, actions, cfg, dtype, dropout_key=None, shard=None):
     else:
         z = torch.as_tensor(np.asarray(obs), dtype=dtype)
         ep = p["VmapStateActionValue_0"]
-    return ensemble_q(ep, z, actions, cfg["critic_layer_norm"])
+    rate = cfg.get("critic_dropout_rate") or 0.0                 # sac_learner.py:47,75-81: MLP(dropout_rate=...)
+    drop = (dropout_key, rate, shard) if (rate > 0 and dropout_key is not None) else None
+    return ensemble_q(ep, z, actions, cfg["critic_layer_norm"], drop)
 
 
 # --------------------------------------------------------------------------- distribution

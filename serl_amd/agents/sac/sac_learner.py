@@ -117,8 +117,8 @@ class SACLearner(Agent):
     @classmethod
     def _build(cls, cfg, seed, actor_lr, critic_lr, temp_lr, discount, tau, num_min_qs, critic_dropout_rate,
                target_entropy, init_temperature, backup_entropy, device, dist, nkeys=4):
-        if critic_dropout_rate:
-            raise NotImplementedError("critic dropout is not used by any SERL config and is not implemented")
+        if critic_dropout_rate is not None and not 0.0 <= float(critic_dropout_rate) < 1.0:
+            raise ValueError("critic_dropout_rate must be in [0, 1)")
         dev = _device(device)
         if target_entropy is None:
             target_entropy = -cfg.action_dim / 2                        # sac_learner.py:60-61
@@ -135,11 +135,13 @@ class SACLearner(Agent):
         self.temp = TempState.create(init_temperature, temp_lr, dev)
         self.tau, self.discount, self.target_entropy = float(tau), float(discount), float(target_entropy)
         self.num_qs, self.num_min_qs, self.backup_entropy = cfg.num_qs, num_min_qs, bool(backup_entropy)
+        self.critic_dropout_rate = critic_dropout_rate
         self._cfg = cfg
         with torch.cuda.device(dev):
             native = NativeLearner(cfg, num_min_qs=num_min_qs, backup_entropy=backup_entropy,
                                    has_temperature=cls._HAS_TEMP, discount=discount, tau=tau,
-                                   target_entropy=target_entropy, actor_lr=actor_lr, critic_lr=critic_lr, temp_lr=temp_lr)
+                                   target_entropy=target_entropy, actor_lr=actor_lr, critic_lr=critic_lr, temp_lr=temp_lr,
+                                   critic_dropout_rate=critic_dropout_rate)
         # shared by every agent copy derived from this one: the driver handle and the (reused) gradient buffers
         self._shared = {"dist": dist, "native": native, "critic_grads": critic_store.zeros_like(),
                         "actor_grads": actor_store.zeros_like()}

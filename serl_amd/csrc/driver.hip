@@ -50,6 +50,7 @@ struct Cfg {
   int encoder;             // 0 TwoD4PGEncoder (trainable conv stack), 1 TwoMobileNetEncoder (frozen backbone + SLE + Dropout)
   int fh, fw, fc;          // feature map the spatial embeddings pool (mobilenet: backbone output; d4pg: last conv layer)
   float enc_drop;          // Dropout rate behind the spatial embeddings (mobilenet encoder, training passes only)
+  float crit_drop;         // critic_dropout_rate: Dropout behind every hidden Dense of the critic MLPs (training applies)
   int aug_rank[MAX_CAM];   // position of (sorted) camera ci in the caller's pixel_keys order: augmentation key order
   float discount, tau, target_entropy, actor_lr, critic_lr, temp_lr;
   int enc_dim, latent, ldz;
@@ -585,16 +586,34 @@ int trunk_bwd(serl_learner* h, char tag, const Store& s, const EncOff& eo, const
 
 // ================================================================= critic ensemble (Ensemble(StateActionValue(MLP)))
 // members m0, m0 + mstride, ... (E of them) on a shared input (B, ld_inp); *q_out = (E, B)
+// nn.Dropout behind hidden layer `layer` of the critic MLPs (mlp.py:26-29) on (E, B, hd) pre-activations or their
+// gradients: member position j takes bernoulli(fold_in(fold_in(key, layer), j), keep) over the (global rows, hd) array
+// (BUILD-DEFINED stream, include/serl_hip.h serl_learner_config.critic_dropout); the same call masks the gradient.
+int critic_dropout(const Cfg& c, const uint32_t* key, int layer, float* x, int E, int B, int hd, int row0, int total,
+                   hipStream_t st) {
+  unsigned kl[2], km[2];
+  DRV(serl_prng_fold_in(key[0], key[1], (unsigned)layer, kl));
+  for (int j = 0; j < E; ++j) {
+    DRV(serl_prng_fold_in(kl[0], kl[1], (unsigned)j, km));
+    DRV(serl_dropout(x + (size_t)j * B * hd, hd, B, hd, km[0], km[1], 1.0f - c.crit_drop, row0, total, st));
+  }
+  return SERL_OK;
+}
+
+// drop: rngs={"dropout": key} of a training=True apply (used only with critic_dropout_rate > 0); row0 / total: global row
+// of this rank's row 0 and the global minibatch size
 int ensemble_fwd(serl_learner* h, char tag, const Store& s, const CriticOff& co, int m0, int mstride, int E,
-                 const float* inp, int ld_inp, int B, Workspace& ws, hipStream_t st, bool save, float** q_out) {
+                 const float* inp, int ld_inp, int B, Workspace& ws, hipStream_t st, bool save, float** q_out,
+                 const uint32_t* drop = nullptr, int row0 = 0, int total = 0) {
   const Cfg& c = h->cfg;
+  if (c.crit_drop <= 0.f) drop = nullptr;
   int din = c.latent + c.crit_A;
   const int nl = c.nh, hl = c.hid[nl - 1];
   const float* a_ptr = inp; long long a_zs = 0, a_ms = ld_inp;
   WSF(ws, st, q, (size_t)E * B, "q_%c", tag);
   const float* head_w = s.at(co.hk) + (long long)m0 * hl;
   const float* head_b = s.at(co.hb) + m0;
-  if (h->ens_fused && nl == 2 && c.hid[0] == 256 && c.hid[1] == 256 && serl_get_matmul_precision() == 1) {
+  if (!drop && h->ens_fused && nl == 2 && c.hid[0] == 256 && c.hid[1] == 256 && serl_get_matmul_precision() == 1) {
     // the whole pass in one launch (ensemble.hip): four dependent launches less on a latency-bound chain
     float *h0 = nullptr, *h1 = nullptr, *xh0 = nullptr, *xh1 = nullptr, *rs0 = nullptr, *rs1 = nullptr;
     if (save) {
@@ -626,7 +645,12 @@ int ensemble_fwd(serl_learner* h, char tag, const Store& s, const CriticOff& co,
       WSF(ws, st, pbuf, (size_t)E * B * hd, "epre%d_%c", i, tag);
       G g; g.a = a_ptr; g.b = W; g.c = pbuf; g.nb = E; g.M = B; g.N = hd; g.K = din; g.a_zs = a_zs; g.a_ms = a_ms; g.a_ks = 1;
       g.b_zs = (long long)mstride * din * hd; g.b_ks = hd; g.b_ns = 1; g.c_zs = (long long)B * hd; g.c_ms = hd;
+      if (drop) { g.bias = bias; g.bias_zs = (long long)mstride * hd; }   // Dense (with bias) -> Dropout -> LayerNorm
       DRV(gemm(g, st));
+      if (drop) {
+        DRV(critic_dropout(c, drop, i, pbuf, E, B, hd, row0, total, st));
+        bias = nullptr;
+      }
       float *xh = nullptr, *rs = nullptr;
       if (save) {
         WSF(ws, st, a, (size_t)E * B * hd, "exh%d_%c", i, tag); xh = a;
@@ -643,8 +667,12 @@ int ensemble_fwd(serl_learner* h, char tag, const Store& s, const CriticOff& co,
     } else {
       G g; g.a = a_ptr; g.b = W; g.c = hbuf; g.bias = bias; g.nb = E; g.M = B; g.N = hd; g.K = din; g.a_zs = a_zs;
       g.a_ms = a_ms; g.a_ks = 1; g.b_zs = (long long)mstride * din * hd; g.b_ks = hd; g.b_ns = 1; g.c_zs = (long long)B * hd;
-      g.c_ms = hd; g.bias_zs = (long long)mstride * hd; g.relu = 1;
+      g.c_ms = hd; g.bias_zs = (long long)mstride * hd; g.relu = drop ? 0 : 1;
       DRV(gemm(g, st));
+      if (drop) {                                                          // Dense -> Dropout -> ReLU
+        DRV(critic_dropout(c, drop, i, hbuf, E, B, hd, row0, total, st));
+        DRV(serl_ln_act_fwd(hbuf, 1, 0, hd, nullptr, nullptr, nullptr, 0, hbuf, hd, nullptr, nullptr, E * B, hd, B, 0, ACT_RELU, st));
+      }
     }
     a_ptr = hbuf; a_zs = (long long)B * hd; a_ms = hd; din = hd;
   }
@@ -657,8 +685,10 @@ int ensemble_fwd(serl_learner* h, char tag, const Store& s, const CriticOff& co,
 // 1 summed (B, latent+action), 2 split-K slabs (the consumer sums them on read).  Result in dinp / nslab / slab_stride.
 int ensemble_bwd(serl_learner* h, char tag, const Store& s, const CriticOff& co, const Store* grads, const float* dq,
                  const float* inp, int ld_inp, int B, Workspace& ws, hipStream_t st, GradSide* gside, int want_dinp,
-                 float** dinp_out, int* nslab_out, long long* ss_out) {
+                 float** dinp_out, int* nslab_out, long long* ss_out, const uint32_t* drop = nullptr, int row0 = 0,
+                 int total = 0) {
   const Cfg& c = h->cfg;
+  if (c.crit_drop <= 0.f) drop = nullptr;
   const int E = c.E, ln = c.ln, nl = c.nh;
   int dims[MAX_HID + 1];
   dims[0] = c.latent + c.crit_A;
@@ -687,6 +717,7 @@ int ensemble_bwd(serl_learner* h, char tag, const Store& s, const CriticOff& co,
       DRV(serl_ln_act_bwd(nullptr, 0, dq, s.at(co.hk), hd, hbuf, hd, xh, rs, gam, hd, dz, g, E * B, hd, B, ln, ACT_RELU, st));
     else
       DRV(serl_ln_act_bwd(dy, hd, nullptr, nullptr, 0, hbuf, hd, xh, rs, gam, hd, dz, g, E * B, hd, B, ln, ACT_RELU, st));
+    if (drop) DRV(critic_dropout(c, drop, i, dz, E, B, hd, row0, total, st));   // gradient w.r.t. the Dense output
     const float* W = s.at(co.w[i]);
     if (grads) {
       float* gb = grads->at(co.b[i]);
@@ -1053,6 +1084,7 @@ extern "C" int serl_learner_create(const serl_learner_config* pc, const long lon
   SERL_CHECK_ARG(!pc->pixel || (pc->num_cameras >= 1 && pc->num_cameras <= MAX_CAM &&
                                 (pc->encoder == 1 || (pc->encoder == 0 && pc->num_conv >= 1 && pc->num_conv <= MAX_CONV))),
                  "learner_create: 1..%d cameras, 1..%d conv layers", MAX_CAM, MAX_CONV);
+  SERL_CHECK_ARG(pc->critic_dropout >= 0.f && pc->critic_dropout < 1.f, "learner_create: critic_dropout must be in [0, 1)");
   serl_learner* h = new serl_learner();
   Cfg& c = h->cfg;
   memset(&c, 0, sizeof(c));
@@ -1064,6 +1096,7 @@ extern "C" int serl_learner_create(const serl_learner_config* pc, const long lon
   c.discount = pc->discount; c.tau = pc->tau; c.target_entropy = pc->target_entropy;
   c.actor_lr = pc->actor_lr; c.critic_lr = pc->critic_lr; c.temp_lr = pc->temp_lr;
   c.encoder = pc->encoder; c.fh = pc->feat_h; c.fw = pc->feat_w; c.fc = pc->feat_c; c.enc_drop = pc->encoder_dropout;
+  c.crit_drop = pc->critic_dropout;
   if (c.pixel && c.encoder == 1) {
     int fh, fw, fc;
     const bool ok = c.stack == 1 && serl_mbv3_feature_shape(c.H, c.W, &fh, &fw, &fc) == SERL_OK && fh == c.fh && fw == c.fw &&
@@ -1337,9 +1370,9 @@ extern "C" int serl_learner_update(serl_learner* h, const serl_agent_buffers* ag
     else DRV(enqueue_actor_obs());
     if (sta != st) DRV_HIP(hipStreamWaitEvent(st, h->adone[i], 0));
     float *next_q, *q;
-    DRV(ensemble_fwd(h, 'T', tstore, co, m0, mstride, emin, zT, ldz, B, ws, st, false, &next_q));
+    DRV(ensemble_fwd(h, 'T', tstore, co, m0, mstride, emin, zT, ldz, B, ws, st, false, &next_q, &step_keys[8 * i + 4], rank * B, Bg));
     if (c.pixel) DRV(serl_copy2d(zC + c.latent, ldz, bt->actions + (size_t)lo * A, A, B, A, s1));
-    DRV(ensemble_fwd(h, 'C', critic, co, 0, 1, E, zC, ldz, B, ws, s1, true, &q));
+    DRV(ensemble_fwd(h, 'C', critic, co, 0, 1, E, zC, ldz, B, ws, s1, true, &q, &step_keys[8 * i + 6], rank * B, Bg));
     DRV(link(s1, st, h->join1));
     DRV(serl_td_loss(next_q, emin, bt->rewards + lo, bt->masks + lo, c.backup_entropy ? nlogp_all + (size_t)i * B : nullptr,
                      log_temp, c.discount, q, E, B, 1.0f / ((float)E * Bg), target_q, dq, info, st));
@@ -1349,7 +1382,8 @@ extern "C" int serl_learner_update(serl_learner* h, const serl_agent_buffers* ag
     // pixel learners: the trunk backward sums the split-K slabs of the input gradient on read; state-based:
     // observations are not trainable, the critic step needs no input gradient at all
     float* dinp = nullptr; int nslab = 1; long long ss = 0;
-    DRV(ensemble_bwd(h, 'C', critic, co, &cgr, dq, zC, ldz, B, ws, st, &h->gside, c.pixel ? 2 : 0, &dinp, &nslab, &ss));
+    DRV(ensemble_bwd(h, 'C', critic, co, &cgr, dq, zC, ldz, B, ws, st, &h->gside, c.pixel ? 2 : 0, &dinp, &nslab, &ss,
+                     &step_keys[8 * i + 6], rank * B, Bg));
     DRV(phase(h, "ensemble_bwd", st));
     DRV(features_bwd(h, 'C', critic, co.e, cgr, f, lo, B, ws, st, dinp, ldz, true, &h->gside, nslab, ss, &step_keys[8 * i + 6]));
     DRV(h->gside.join());
@@ -1373,11 +1407,11 @@ extern "C" int serl_learner_update(serl_learner* h, const serl_agent_buffers* ag
     DRV(features(h, &p, 1, f, lo, B, ws, st, 0, nullptr, true));
   }
   float* q;
-  DRV(ensemble_fwd(h, 'C', critic, co, 0, 1, E, zP, ldz, B, ws, st, true, &q));
+  DRV(ensemble_fwd(h, 'C', critic, co, 0, 1, E, zP, ldz, B, ws, st, true, &q, key_drop_pi, rank * B, Bg));
   DRV(serl_actor_loss(q, E, B, logpA, log_temp, info + 2, st));
   DRV(serl_fill(dq, -1.0f / ((float)E * Bg), (long long)E * B, st));
   float* dinp = nullptr; int nslab = 1; long long ss = 0;
-  DRV(ensemble_bwd(h, 'C', critic, co, nullptr, dq, zP, ldz, B, ws, st, nullptr, 1, &dinp, &nslab, &ss));
+  DRV(ensemble_bwd(h, 'C', critic, co, nullptr, dq, zP, ldz, B, ws, st, nullptr, 1, &dinp, &nslab, &ss, key_drop_pi, rank * B, Bg));
   WSF(ws, st, dms, (size_t)B * 2 * A, "dms");
   WSF(ws, st, msA, (size_t)B * 2 * A, "ms_A");
   WSF(ws, st, epsA, (size_t)B * A, "eps_A");

@@ -17,6 +17,18 @@ class DataParallel:
         self.group = group
         self.rank = td.get_rank(group)
         self.world_size = td.get_world_size(group)
+        # bench.py instrumentation: with `timing` set, every device all-reduce is bracketed by events on the caller's
+        # stream (RCCL) or timed on the host (gloo); `allreduce_seconds` sums them (synchronise first)
+        self.timing = False
+        self._pairs = []
+        self._host_s = 0.0
+
+    @property
+    def allreduce_seconds(self) -> float:
+        return self._host_s + sum(a.elapsed_time(b) for a, b in self._pairs) * 1e-3
+
+    def timing_reset(self):
+        self._pairs, self._host_s = [], 0.0
 
     def all_reduce_sum(self, tensor):
         if self.world_size > 1:
@@ -25,9 +37,21 @@ class DataParallel:
                 # Two ranks on one GPU (tools/rehearse_dp.sh) stalled in that staging for minutes now and then -- with the
                 # update's kernels queued behind it, and at full size even with the device idle -- so the host copy is made
                 # here, on the caller's stream, and gloo only ever sees host memory.  RCCL ("nccl") is not affected.
+                import time
+                t0 = time.perf_counter()
                 host = tensor.cpu()
                 self._td.all_reduce(host, op=self._td.ReduceOp.SUM, group=self.group)
                 tensor.copy_(host)
+                if self.timing:
+                    self._host_s += time.perf_counter() - t0
+                return tensor
+            if self.timing and tensor.is_cuda:
+                import torch
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                self._td.all_reduce(tensor, op=self._td.ReduceOp.SUM, group=self.group)
+                b.record()
+                self._pairs.append((a, b))
                 return tensor
             self._td.all_reduce(tensor, op=self._td.ReduceOp.SUM, group=self.group)
         return tensor

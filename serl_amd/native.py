@@ -29,7 +29,8 @@ class LearnerConfig(C.Structure):
                 ("cnn_filters", C.c_int * 8), ("cnn_strides", C.c_int * 8), ("aug_rank", C.c_int * 4),
                 ("discount", C.c_float), ("tau", C.c_float), ("target_entropy", C.c_float), ("actor_lr", C.c_float),
                 ("critic_lr", C.c_float), ("temp_lr", C.c_float), ("encoder", C.c_int), ("feat_h", C.c_int),
-                ("feat_w", C.c_int), ("feat_c", C.c_int), ("encoder_dropout", C.c_float), ("critic_no_action", C.c_int)]
+                ("feat_w", C.c_int), ("feat_c", C.c_int), ("encoder_dropout", C.c_float), ("critic_no_action", C.c_int),
+                ("critic_dropout", C.c_float)]
 
 
 class AgentBuffers(C.Structure):
@@ -67,7 +68,8 @@ def _offsets(layout):
 
 class NativeLearner:
     def __init__(self, cfg: NetConfig, *, num_min_qs, backup_entropy, has_temperature, discount, tau, target_entropy,
-                 actor_lr, critic_lr, temp_lr, critic_layout_fn=critic_layout, critic_no_action=False):
+                 actor_lr, critic_lr, temp_lr, critic_layout_fn=critic_layout, critic_no_action=False,
+                 critic_dropout_rate=None):
         if len(cfg.hidden_dims) > 4:
             raise ValueError("at most 4 hidden layers")
         lc = LearnerConfig()
@@ -93,6 +95,7 @@ class NativeLearner:
         lc.discount, lc.tau, lc.target_entropy = float(discount), float(tau), float(target_entropy)
         lc.actor_lr, lc.critic_lr, lc.temp_lr = float(actor_lr or 0.0), float(critic_lr or 0.0), float(temp_lr or 0.0)
         lc.critic_no_action = int(bool(critic_no_action))      # hybrid BC: the "critic" slot is the discrete actor
+        lc.critic_dropout = float(critic_dropout_rate or 0.0)
         co, nco = _offsets(critic_layout_fn(cfg))
         ao, nao = _offsets(actor_layout(cfg))
         h = C.c_void_p()

@@ -97,7 +97,8 @@ def agent_to_oracle(agent):
     ocfg = dict(discount=agent.discount, tau=agent.tau, target_entropy=agent.target_entropy, num_qs=agent.num_qs,
                 num_min_qs=agent.num_min_qs, backup_entropy=agent.backup_entropy, actor_lr=agent.actor.lr,
                 critic_lr=agent.critic.lr, temp_lr=agent.temp.lr, critic_layer_norm=cfg.critic_layer_norm,
-                pixel_keys=cfg.pixel_keys, cnn_strides=cfg.cnn_strides)
+                pixel_keys=cfg.pixel_keys, cnn_strides=cfg.cnn_strides,
+                critic_dropout_rate=getattr(agent, "critic_dropout_rate", None))
     if getattr(cfg, "encoder", "d4pg") == "mobilenet":
         ocfg.update(encoder="mobilenet", backbone=agent._shared["backbone"].tree(), encoder_dropout=cfg.encoder_dropout)
     return state, ocfg

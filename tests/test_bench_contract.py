@@ -29,6 +29,9 @@ def test_bench_json_contract(dev):
         assert k in r, k
     assert r["bound"] in ("hbm", "mfma") and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert r["traffic"] is None or r["traffic"] >= 0.9 * r["algorithmic_bytes_per_launch"]
+    # the other configurations the target is stated on (BASELINE configs 2, 4, 5), as extra keys
+    assert d["c2_us_per_grad_step"] > 0 and d["c4_value"] > 0 and d["c5_1gpu_value"] > 0 and d["host_cpu_ms_per_step"] > 0
+    assert 0 < d["c4_roofline"]["frac"] < 1
 
 
 @pytest.mark.gpu
@@ -44,5 +47,7 @@ def test_bench_two_ranks_rehearsal(dev):
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["rehearsal"] is True and d["metric"].startswith("REHEARSAL") and d["ranks_seen"] == 2
+    assert d["allreduce_ms_per_step"] > 0
     # 2 grad-steps per update on each of 2 ranks of 32 rows, normalised to 256-row batches
     assert abs(d["value"] - 2 * 2 * 1000.0 / d["ms_per_step"] * (32 / 256.0)) <= 1e-2 * d["value"]

@@ -45,7 +45,7 @@ def _check_grads(agent, name, ref64, ref32, prec, rtol, noise_ref=None):
         assert_tree_close(got, ref, rtol=5e-2, l2_rtol=2e-2 if noise_ref is not None else 3e-2, what=name)
 
 
-@pytest.mark.parametrize("cfgname", ["sac_c1", "rlpd_u1", "rlpd_c2", "redq_m3"])
+@pytest.mark.parametrize("cfgname", ["sac_c1", "rlpd_u1", "rlpd_c2", "redq_m3", "droq_ln", "droq_plain"])
 def test_state_learner_matches_oracle(dev, cfgname, prec):
     from oracle import learner as ol
     from serl_amd.agents import SACLearner
@@ -59,6 +59,12 @@ def test_state_learner_matches_oracle(dev, cfgname, prec):
     elif cfgname == "rlpd_c2":    # BASELINE config 2 (UTD shortened for the CPU oracle)
         kw = dict(num_qs=10, num_min_qs=2, critic_layer_norm=True, backup_entropy=False, init_temperature=0.1)
         B, U = 256, 4
+    elif cfgname.startswith("droq"):   # critic_dropout_rate (sac_learner.py:47, mlp.py:26-29): Dense -> Dropout -> [LN] -> ReLU in
+        # the target / critic / actor-step applies; mask stream build-defined (oracle.learner.critic_dropout)
+        kw = dict(num_qs=2 if cfgname == "droq_plain" else 4, num_min_qs=None if cfgname == "droq_plain" else 2,
+                  critic_layer_norm=cfgname == "droq_ln", critic_dropout_rate=0.01 if cfgname == "droq_ln" else 0.2,
+                  backup_entropy=True, init_temperature=0.5)
+        B, U = 96, (1 if cfgname == "droq_ln" else 2)
     else:                          # general subsample path (non-arithmetic index sets)
         kw = dict(num_qs=6, num_min_qs=3, critic_layer_norm=True, backup_entropy=True, init_temperature=0.5)
         B, U = 64, 3
@@ -95,7 +101,7 @@ def test_state_learner_matches_oracle(dev, cfgname, prec):
     assert np.array_equal(agent.rng, ostate["rng"])
 
 
-@pytest.mark.parametrize("variant", ["e1_packed", "e1_packed_utd2", "e0_unpacked_small"])
+@pytest.mark.parametrize("variant", ["e1_packed", "e1_packed_utd2", "e0_unpacked_small", "e0_small_droq"])
 def test_drq_learner_matches_oracle(dev, variant, prec):
     from oracle import learner as ol
     from serl_amd.agents import DrQLearner
@@ -107,6 +113,8 @@ def test_drq_learner_matches_oracle(dev, variant, prec):
     else:                           # DrQLearner defaults (stride 2,1,1,1), stack 1, unpacked batch
         H = W = 32; S = 1; B, U = 6, 1
         kw = dict(num_qs=2, critic_layer_norm=False, backup_entropy=True)
+        if variant.endswith("droq"):           # pixel learner with critic_dropout_rate (drq_learner.py:47,100-106)
+            kw = dict(num_qs=4, num_min_qs=2, critic_layer_norm=True, backup_entropy=False, critic_dropout_rate=0.05)
         packed = False
     keys = ("wrist_1", "wrist_2")
     obs_space, act_space = pixel_spaces(keys, H, W, S, 19, 7)
