@@ -169,6 +169,7 @@ struct serl_learner {
   bool timing = false, phases = false;
   int wg_main_layers = getenv("SERL_AMD_WG_MAIN_LAYERS") ? atoi(getenv("SERL_AMD_WG_MAIN_LAYERS")) : 1;   // A/B switch
   bool ens_fused = getenv("SERL_AMD_ENS_FUSED") == nullptr || strcmp(getenv("SERL_AMD_ENS_FUSED"), "0") != 0;   // A/B switch
+  bool ens_bwd_fused = getenv("SERL_AMD_ENS_BWD_FUSED") == nullptr || strcmp(getenv("SERL_AMD_ENS_BWD_FUSED"), "0") != 0;   // A/B switch
   bool fuse12 = getenv("SERL_AMD_CONV_FUSE12") == nullptr || strcmp(getenv("SERL_AMD_CONV_FUSE12"), "0") != 0;   // A/B switch
   std::vector<TimeRec> trecs;
   std::vector<PhaseRec> precs;
@@ -695,11 +696,66 @@ int ensemble_bwd(serl_learner* h, char tag, const Store& s, const CriticOff& co,
   for (int i = 0; i < nl; ++i) dims[i + 1] = c.hid[i];
   const int hl = dims[nl];
   hipStream_t stw = st;
-  if (grads) {
+  const bool fused_ = !drop && h->ens_bwd_fused && nl == 2 && c.hid[0] == 256 && c.hid[1] == 256 && serl_get_matmul_precision() == 1;
+  if (grads && !fused_) {
     if (gside) DRV(gside->fork(&stw));
     WSF(ws, st, hlast, (size_t)E * B * hl, "h%d_%c", nl - 1, tag);
     DRV(colsum(hlast, grads->at(co.hk), E, B, hl, hl, hl, stw, dq));
     DRV(colsum(dq, grads->at(co.hb), E, B, 1, 1, 1, stw));
+  }
+  if (fused_) {
+    // one launch for ln_act_bwd + GEMM + ln_act_bwd, one for every batch-column sum (csrc/ensemble.hip)
+    const size_t nel = (size_t)E * B * 256;
+    WSF(ws, st, h0, nel, "h0_%c", tag);
+    WSF(ws, st, h1, nel, "h1_%c", tag);
+    WSF(ws, st, dz1, nel, "edz1");
+    WSF(ws, st, dz0, nel, "edz0");
+    float *g1 = nullptr, *g0 = nullptr, *xh0 = nullptr, *xh1 = nullptr, *rs0 = nullptr, *rs1 = nullptr;
+    if (ln) {
+      WSF(ws, st, a1, nel, "eg1"); g1 = a1;
+      WSF(ws, st, a0, nel, "eg0"); g0 = a0;
+      WSF(ws, st, x0, nel, "exh0_%c", tag); xh0 = x0;
+      WSF(ws, st, x1, nel, "exh1_%c", tag); xh1 = x1;
+      WSF(ws, st, r0, (size_t)E * B, "ers0_%c", tag); rs0 = r0;
+      WSF(ws, st, r1, (size_t)E * B, "ers1_%c", tag); rs1 = r1;
+    }
+    DRV(serl_ensemble_bwd_fused(dq, B, E, s.at(co.hk), s.at(co.w[1]), ln ? s.at(co.lns[0]) : nullptr,
+                                ln ? s.at(co.lns[1]) : nullptr, ln, h0, h1, xh0, xh1, rs0, rs1, dz1, g1, dz0, g0, st));
+    if (grads) {
+      if (gside) DRV(gside->fork(&stw));
+      DRV(serl_ensemble_colsum(dq, h1, g1, xh1, dz1, g0, xh0, dz0, B, E, ln, grads->at(co.hk), grads->at(co.hb),
+                               ln ? grads->at(co.lnb[1]) : nullptr, ln ? grads->at(co.lns[1]) : nullptr, grads->at(co.b[1]),
+                               ln ? grads->at(co.lnb[0]) : nullptr, ln ? grads->at(co.lns[0]) : nullptr, grads->at(co.b[0]), stw));
+      for (int i = 1; i >= 0; --i) {      // dW_i[e] = (input of layer i)^T . dz_i[e]
+        const int hp = dims[i];
+        const float* a_ptr = i == 0 ? inp : h0;
+        G gg; gg.a = a_ptr; gg.b = i == 0 ? dz0 : dz1; gg.c = grads->at(co.w[i]); gg.nb = E; gg.M = hp; gg.N = 256; gg.K = B;
+        gg.a_zs = i == 0 ? 0 : (long long)B * 256; gg.a_ms = 1; gg.a_ks = i == 0 ? ld_inp : 256; gg.b_zs = (long long)B * 256;
+        gg.b_ks = 256; gg.b_ns = 1; gg.c_zs = (long long)hp * 256; gg.c_ms = 256; gg.a_kc = 0;
+        DRV(gemm(gg, stw));
+      }
+    }
+    if (want_dinp == 0) return SERL_OK;
+    const int hp = dims[0], hd = 256;
+    const float* W = s.at(co.w[0]);
+    const float* dz = dz0;
+    WSF(ws, st, dinp, (size_t)B * hp, "dinp");
+    const int ns = ksplit(E * hd);
+    G gg; gg.a = dz; gg.b = W; gg.M = B; gg.N = hp; gg.K = E * hd; gg.seglen = hd; gg.a_ss = (long long)B * hd; gg.a_ms = hd;
+    gg.a_ks = 1; gg.b_ss = (long long)hp * hd; gg.b_ks = 1; gg.b_ns = hd; gg.c_ms = hp; gg.b_nc = 0;
+    if (ns > 1) {
+      WSF(ws, st, slab, (size_t)ns * B * hp, "dinp_slab");
+      gg.c = slab; gg.nsplit = ns; gg.c_split = (long long)B * hp;
+      DRV(gemm(gg, st));
+      if (want_dinp == 2) { *dinp_out = slab; *nslab_out = ns; *ss_out = (long long)B * hp; return SERL_OK; }
+      DRV(serl_ln_act_fwd(slab, ns, (long long)B * hp, hp, nullptr, nullptr, nullptr, 0, dinp, hp, nullptr, nullptr, B, hp,
+                          B, 0, ACT_NONE, st));
+    } else {
+      gg.c = dinp;
+      DRV(gemm(gg, st));
+    }
+    *dinp_out = dinp; *nslab_out = 1; *ss_out = 0;
+    return SERL_OK;
   }
   const float* dy = nullptr;
   for (int i = nl - 1; i >= 0; --i) {

@@ -28,6 +28,21 @@ constexpr int E_XPART = EBM * E_LDKW_X, E_HPART = EBM * E_LDKW_H, E_WPART = (EBK
 constexpr int E_LDC = EH + 4;            // floats per row of the fp32 tile
 constexpr int E_LDS = (4 * E_XPART + 2 * E_HPART + 4 * E_WPART + EBM * E_LDC) * 4;   // two x / weight slab buffers
 
+// XCD-aware block -> (member, row block) map of the fused backward kernel.  Every block of a member streams that member's whole
+// kernel (256 KB for a hidden layer): workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share one,
+// MI355X_MICROARCH.md), so with a plain (row block, member) grid of 8 row blocks every XCD sees every member exactly once
+// -- no L2 reuse, E x 256 KB per XCD from the fabric.  Here all row blocks of member e run on XCD slot e % 8: the kernel
+// is fetched once per member and the other row blocks hit the XCD's L2.  Grid = 8 * ceil(E / 8) * nrb blocks; blocks
+// whose member index falls past E exit at once.  Placement is a speed matter only (no block depends on another).
+__device__ __forceinline__ bool ens_block_map(int E, int nrb, int& e, int& row_base) {
+  const int b = blockIdx.x, k = b & 7, j = b >> 3;
+  const int m = j / nrb, rb = j - m * nrb;
+  e = k + 8 * m;
+  row_base = rb * EBM;
+  return e < E;
+}
+static inline unsigned ens_grid(int E, int B) { return 8u * (unsigned)cdiv(E, 8) * (unsigned)cdiv(B, EBM); }
+
 __device__ __forceinline__ float ens_wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -35,7 +50,7 @@ __device__ __forceinline__ float ens_wave_sum(float v) {
 }
 
 struct EnsFwdArgs {
-  const float* inp; int ld_inp, din, B;
+  const float* inp; int ld_inp, din, B, E;
   const float *w0, *b0, *g0, *be0, *w1, *b1, *g1, *be1, *hw, *hb;   // member 0 of the launch; member e at e * stride
   long long w0_ms, w1_ms, v_ms, hb_ms;                              // member strides (floats): kernels, 256-vectors, head bias
   int use_ln;
@@ -203,6 +218,8 @@ __global__ __launch_bounds__(ENT, 1) void ens_fwd_kernel(const EnsFwdArgs a) {
   uint32_t* const Ws = Xs + 4 * E_XPART;             // [buf][hi, lo][16][E_LDW]
   uint32_t* const Hs = Ws + 4 * E_WPART;             // [hi, lo][32][E_LDKW_H]
   float* const Cs = reinterpret_cast<float*>(Hs + 2 * E_HPART);
+  // (plain grid: the ring below already spreads a block's weight fetch over its whole run time; the XCD-aware map of the
+  // backward kernel measured 1 us SLOWER here -- 16 blocks of two members share one XCD's L2 ports)
   const int e = blockIdx.y, row_base = blockIdx.x * EBM;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -303,6 +320,256 @@ __global__ __launch_bounds__(ENT, 1) void ens_fwd_kernel(const EnsFwdArgs a) {
               nullptr, a.hw + vo, a.hb + e * a.hb_ms, a.q + ro);
 }
 
+
+// ================================================================= fused backward
+// Backward of the same ensemble from dq (E, B) down to the gradient of the first Dense's output, in ONE launch:
+//   g1 = dq . hw[e] * (h1 > 0);  dz1 = LN'(g1; xh1, rs1, gamma1)        (the arithmetic of ln_act_bwd_kernel, rank-1 form)
+//   dh0 = dz1 . W1[e]^T                                                 (bf16_3x MFMA, K = 256)
+//   g0 = dh0 * (h0 > 0);          dz0 = LN'(g0; xh0, rs0, gamma0)
+// replacing ln_act_bwd + GEMM + ln_act_bwd (three dependent launches of a latency-bound chain).  dz1, dz0 (and g1, g0 with
+// LayerNorm) go to HBM for the parameter-gradient kernels (dW GEMMs, ens_colsum_kernel below) and the input gradient.
+// A block owns 32 rows of one member.  The whole of W1[e] -- 128 registers per thread, 8 contraction slabs x 4 float4 --
+// is requested before anything else, so the loads land while the first LayerNorm backward runs; the K loop has no
+// global load in it.
+struct EnsBwdArgs {
+  const float* dq; const float* hw; long long v_ms;     // (E, B); head kernel (member e at e * v_ms, as every 256-vector)
+  const float *h1, *xh1, *rs1, *g1s;                    // layer 1: activations (E,B,256), x-hat, 1/sigma (E,B), LN scale
+  const float* w1; long long w1_ms;                     // (256, 256) row-major [k][n], member stride
+  const float *h0, *xh0, *rs0, *g0s;                    // layer 0
+  float *dz1, *g1, *dz0, *g0;                           // outputs (E, B, 256); g1 / g0 only with LayerNorm
+  int B, use_ln, width, E;
+};
+
+// Inputs of the LayerNorm backward of the wave's rows [4 wid, 4 wid + 4), loaded ahead of their use: global loads retire in
+// order, so what a phase needs is requested BEFORE the next burst of loads (the weights) and waited for with a counted
+// vmcnt while that burst is still in flight.
+struct EnsLnIn { float y[ENR][4], xh[ENR][4], rs[ENR], dq[ENR], ga[4], hv[4]; };
+__device__ __forceinline__ void ens_ln_bwd_load(EnsLnIn& in, const float* dq, const float* hw, int wid, int lane, int row_base,
+                                                int B, const float* y, const float* xhat, const float* rstd,
+                                                const float* gamma, int use_ln) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int n = lane + 64 * i;
+    in.ga[i] = use_ln ? gamma[n] : 1.f;
+    in.hv[i] = hw ? hw[n] : 0.f;
+  }
+#pragma unroll
+  for (int rr = 0; rr < ENR; ++rr) {
+    const int grow = min(row_base + wid * ENR + rr, B - 1);     // clamped: rows past B are computed and dropped
+    in.dq[rr] = dq ? dq[grow] : 0.f;
+    in.rs[rr] = use_ln ? rstd[grow] : 1.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int n = lane + 64 * i;
+      in.y[rr][i] = y[(long long)grow * EH + n];
+      in.xh[rr][i] = use_ln ? xhat[(long long)grow * EH + n] : 0.f;
+    }
+  }
+}
+
+// rows [4 wid, 4 wid + 4) of the block: g = dy * (y > 0), LayerNorm backward (the arithmetic of ln_act_bwd_kernel); results
+// to HBM and (img != nullptr) as the bf16 hi / lo A operand of the next GEMM.  dy = dq[row] * hw[n] (Cs == nullptr) or the
+// fp32 tile Cs.
+__device__ __forceinline__ void ens_ln_bwd_rows(const EnsLnIn& in, const float* Cs, int wid, int lane, int row_base, int B,
+                                                int use_ln, int width, float* dz_out, float* g_out, uint32_t* img) {
+  float gv[ENR][4], s1[ENR], s2[ENR];
+#pragma unroll
+  for (int rr = 0; rr < ENR; ++rr) {
+    const int row = wid * ENR + rr;
+    s1[rr] = 0.f; s2[rr] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int n = lane + 64 * i;
+      const float d = Cs ? Cs[row * E_LDC + n] : in.dq[rr] * in.hv[i];
+      const float g = in.y[rr][i] > 0.f ? d : 0.f;
+      if (use_ln) {
+        const float dxh = g * in.ga[i];
+        s1[rr] += dxh;
+        s2[rr] += dxh * in.xh[rr][i];
+      }
+      gv[rr][i] = g;
+    }
+  }
+  if (use_ln) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+      for (int rr = 0; rr < ENR; ++rr) {
+        s1[rr] += __shfl_xor(s1[rr], o);
+        s2[rr] += __shfl_xor(s2[rr], o);
+      }
+  }
+#pragma unroll
+  for (int rr = 0; rr < ENR; ++rr) {
+    const int row = wid * ENR + rr, grow = row_base + row;
+    const bool ok = grow < B;
+    float m1 = 0.f, m2 = 0.f;
+    if (use_ln) {
+      m1 = s1[rr] / (float)width;
+      m2 = s2[rr] / (float)width;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int n = lane + 64 * i;
+      float dz = gv[rr][i];
+      if (use_ln) dz = in.rs[rr] * (gv[rr][i] * in.ga[i] - m1 - in.xh[rr][i] * m2);
+      if (!ok) dz = 0.f;
+      if (ok) {
+        dz_out[(long long)grow * EH + n] = dz;
+        if (use_ln) g_out[(long long)grow * EH + n] = gv[rr][i];
+      }
+      if (img) {
+        uint32_t hi, lo;
+        split_pair(dz, 0.f, hi, lo);
+        unsigned short* d = reinterpret_cast<unsigned short*>(img + row * E_LDKW_H) + n;
+        d[0] = (unsigned short)hi;
+        d[2 * E_HPART] = (unsigned short)lo;
+      }
+    }
+  }
+}
+
+constexpr int EB_LDS = (2 * E_HPART + 4 * E_WPART + EBM * E_LDC) * 4;
+
+__global__ __launch_bounds__(ENT, 1) void ens_bwd_kernel(const EnsBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t e_smem[];
+  uint32_t* const Hs = e_smem;                        // [hi, lo][32][E_LDKW_H]: dz1 as the A operand
+  uint32_t* const Ws = Hs + 2 * E_HPART;              // [buf][hi, lo][16 k pairs][E_LDW]: W1^T slabs
+  float* const Cs = reinterpret_cast<float*>(Ws + 4 * E_WPART);
+  int e, row_base;
+  if (!ens_block_map(a.E, (a.B + EBM - 1) / EBM, e, row_base)) return;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const long long vo = e * a.v_ms, ro = (long long)e * a.B;
+  // ---- layer 1's LayerNorm inputs first (see EnsLnIn), then all of this thread's share of W1[e]: for each of the 8
+  // contraction slabs (32 n), rows wr + 64 j, columns 4 c4 .. + 3 of the slab -- 8 consecutive lanes read one 128-byte row
+  // segment (full cache lines per wave instruction)
+  EnsLnIn in;
+  ens_ln_bwd_load(in, a.dq + ro, a.hw + vo, wid, lane, row_base, a.B, a.h1 + ro * EH, a.use_ln ? a.xh1 + ro * EH : nullptr,
+                  a.use_ln ? a.rs1 + ro : nullptr, a.use_ln ? a.g1s + vo : nullptr, a.use_ln);
+  __builtin_amdgcn_sched_barrier(0);
+  const int wr = tid >> 3, c4 = tid & 7;
+  const float* wbase = a.w1 + e * a.w1_ms + (long long)wr * EH + 4 * c4;
+  float4 wv[8][4];
+#pragma unroll
+  for (int sl = 0; sl < 8; ++sl)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#ifdef EB_NO_W      // ablation build: no weight traffic
+      wv[sl][j] = make_float4(0.01f * (float)c4, 0.f, 0.02f, 0.f);
+#else
+      wv[sl][j] = *reinterpret_cast<const float4*>(wbase + (long long)(64 * j) * EH + sl * EBK);
+#endif
+    }
+  __builtin_amdgcn_sched_barrier(0);                  // issue the loads here, not at their first use
+  // ---- layer 1: dq . hw -> dz1 (HBM + LDS image)
+  ens_ln_bwd_rows(in, nullptr, wid, lane, row_base, a.B, a.use_ln, a.width, a.dz1 + ro * EH, a.use_ln ? a.g1 + ro * EH : nullptr, Hs);
+  // ---- dh0 = dz1 . W1^T: slab sl = contraction indices n in [32 sl, 32 sl + 32); image [n pair][kk]
+  auto store = [&](int sl, int buf) {
+    uint32_t* img = Ws + buf * 2 * E_WPART;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      uint32_t h0, l0, h1, l1;
+      split_pair(wv[sl][j].x, wv[sl][j].y, h0, l0);
+      split_pair(wv[sl][j].z, wv[sl][j].w, h1, l1);
+      uint32_t* d = img + (2 * c4) * E_LDW + wr + 64 * j;
+      d[0] = h0; d[E_LDW] = h1;
+      d[E_WPART] = l0; d[E_WPART + E_LDW] = l1;
+    }
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+  store(0, 0);
+  __syncthreads();                                    // the dz1 image and slab 0 are complete
+#pragma unroll
+  for (int sl = 0; sl < 8; ++sl) {
+    if (sl + 1 < 8) store(sl + 1, (sl + 1) & 1);
+    if (sl == 6) {                                    // every weight register is dead: request layer 0's LayerNorm inputs
+      ens_ln_bwd_load(in, nullptr, nullptr, wid, lane, row_base, a.B, a.h0 + ro * EH, a.use_ln ? a.xh0 + ro * EH : nullptr,
+                      a.use_ln ? a.rs0 + ro : nullptr, a.use_ln ? a.g0s + vo : nullptr, a.use_ln);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    ens_mma(Hs, E_HPART, E_LDKW_H, sl * (EBK / 2), Ws + (sl & 1) * 2 * E_WPART, wid, r, h, acc);
+    __syncthreads();
+  }
+  ens_acc_to_tile(Cs, wid, r, h, acc);
+  __syncthreads();
+  // ---- layer 0
+  ens_ln_bwd_rows(in, Cs, wid, lane, row_base, a.B, a.use_ln, a.width, a.dz0 + ro * EH, a.use_ln ? a.g0 + ro * EH : nullptr, nullptr);
+}
+
+// Batch-column sums of the ensemble's backward in ONE launch (were two launches for the head and one per layer):
+//   job 0: d hw[e][n] = sum_b dq[e,b] h1[e,b,n],  d hb[e] = sum_b dq[e,b]
+//   job 1 + l: d LNbias_l = sum_b g_l,  d LNscale_l = sum_b g_l xh_l,  d bias_l = sum_b dz_l      (no LayerNorm: d bias_l only)
+// Block (e, job, 64-column quarter): 1024 threads = 16 row groups x 64 columns; the partial sums are added in a fixed order.
+struct EnsColsumArgs {
+  const float *dq, *h1, *g1, *xh1, *dz1, *g0, *xh0, *dz0;
+  float *d_hw, *d_hb, *d_lnb1, *d_lns1, *d_b1, *d_lnb0, *d_lns0, *d_b0;   // member e at e * 256 (d_hb: e)
+  int B, use_ln;
+};
+constexpr int CS_RG = 16, CS_COLS = 64;     // row groups x columns of a block: 1024 threads
+__global__ __launch_bounds__(CS_RG * CS_COLS) void ens_colsum_kernel(const EnsColsumArgs a) {
+  __shared__ float part[3][CS_RG][CS_COLS];
+  const int e = blockIdx.x, job = blockIdx.y, cl = threadIdx.x & (CS_COLS - 1), rg = threadIdx.x / CS_COLS;
+  const int n = blockIdx.z * CS_COLS + cl;
+  const long long ro = (long long)e * a.B;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  // rows rg, rg + 16, ...: eight rows per trip with their loads issued together (a rolled loop is one memory round trip
+  // per row); rows past B read row B - 1 with weight 0
+  const float* p0 = job == 0 ? a.h1 : (job == 1 ? a.g1 : a.g0);
+  const float* p1 = job == 0 ? nullptr : (job == 1 ? a.xh1 : a.xh0);
+  const float* p2 = job == 0 ? nullptr : (job == 1 ? a.dz1 : a.dz0);
+  const bool ln = a.use_ln != 0;
+  for (int b0 = rg; b0 < a.B; b0 += 8 * CS_RG) {
+    float v0[8], v1[8], v2[8], w[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int b = b0 + u * CS_RG;
+      const long long at = (ro + min(b, a.B - 1)) * EH + n;
+      w[u] = b < a.B ? 1.f : 0.f;
+      v0[u] = (job == 0 || ln) ? p0[at] : 0.f;
+      v1[u] = (job != 0 && ln) ? p1[at] : 0.f;
+      v2[u] = job != 0 ? p2[at] : a.dq[ro + min(b, a.B - 1)];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (job == 0) {
+        const float d = v2[u] * w[u];
+        s0 = fmaf(d, v0[u], s0);
+        s1 += d;
+      } else {
+        const float g = v0[u] * w[u];
+        s0 += g;
+        s1 = fmaf(g, v1[u], s1);
+        s2 += v2[u] * w[u];
+      }
+    }
+  }
+  part[0][rg][cl] = s0; part[1][rg][cl] = s1; part[2][rg][cl] = s2;
+  __syncthreads();
+  if (rg != 0) return;
+  float t[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    float acc = part[q][0][cl];
+#pragma unroll
+    for (int i = 1; i < CS_RG; ++i) acc += part[q][i][cl];
+    t[q] = acc;
+  }
+  const long long vo = (long long)e * EH + n;
+  if (job == 0) {
+    a.d_hw[vo] = t[0];
+    if (n == 0) a.d_hb[e] = t[1];
+  } else {
+    if (ln) {
+      (job == 1 ? a.d_lnb1 : a.d_lnb0)[vo] = t[0];
+      (job == 1 ? a.d_lns1 : a.d_lns0)[vo] = t[1];
+    }
+    (job == 1 ? a.d_b1 : a.d_b0)[vo] = t[2];
+  }
+}
+
 }  // namespace
 
 // E members (member e at the given strides from the pointers of the first one) on a shared input inp (B, ld_inp) whose
@@ -330,7 +597,7 @@ extern "C" int serl_ensemble_fwd_fused(const float* inp, int ld_inp, int din, in
       SERL_CHECK_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, E_LDS), "ensemble_fwd_fused");
     opted[dev] = true;
   }
-  EnsFwdArgs a{inp, ld_inp, din, B, w0, b0, g0, be0, w1, b1, g1, be1, hw, hb, w0_member_stride, w1_member_stride,
+  EnsFwdArgs a{inp, ld_inp, din, B, E, w0, b0, g0, be0, w1, b1, g1, be1, hw, hb, w0_member_stride, w1_member_stride,
                vec_member_stride, head_bias_member_stride, use_ln, EH, h0, h1, xh0, xh1, rs0, rs1, q};
   const dim3 grid(cdiv(B, EBM), E);
   hipStream_t st = (hipStream_t)stream;
@@ -341,5 +608,46 @@ extern "C" int serl_ensemble_fwd_fused(const float* inp, int ld_inp, int din, in
     default: hipLaunchKernelGGL(ens_fwd_kernel<3>, grid, dim3(ENT), E_LDS, st, a); break;
   }
   SERL_CHECK_LAUNCH("ensemble_fwd_fused");
+  return SERL_OK;
+}
+
+// Backward of serl_ensemble_fwd_fused's network for ALL E members (member stride = one member, the critic's own layout) from
+// dq (E, B): dz1 / dz0 = gradients w.r.t. the outputs of the second / first Dense, g1 / g0 = gradients w.r.t. the
+// LayerNorm outputs (use_ln only).  Precision "bf16_3x" only.
+extern "C" int serl_ensemble_bwd_fused(const float* dq, int B, int E, const float* hw, const float* w1, const float* g0s,
+                                       const float* g1s, int use_ln, const float* h0, const float* h1, const float* xh0,
+                                       const float* xh1, const float* rs0, const float* rs1, float* dz1, float* g1,
+                                       float* dz0, float* g0, void* stream) {
+  SERL_CHECK_ARG(dq && hw && w1 && h0 && h1 && dz1 && dz0, "ensemble_bwd_fused: null pointer");
+  SERL_CHECK_ARG(B >= 1 && E >= 1, "ensemble_bwd_fused: bad shape");
+  SERL_CHECK_ARG(!use_ln || (g0s && g1s && xh0 && xh1 && rs0 && rs1 && g1 && g0), "ensemble_bwd_fused: LayerNorm needs scale, x-hat, 1/sigma and the g outputs");
+  SERL_CHECK_ARG(serl_get_matmul_precision() == 1, "ensemble_bwd_fused: bf16_3x precision only");
+  SERL_CHECK_ARG(((uintptr_t)w1 & 15) == 0, "ensemble_bwd_fused: kernel must be 16-byte aligned");
+  static_assert(EB_LDS <= 160 * 1024, "LDS");
+  static bool opted[64] = {};
+  int dev = 0;
+  SERL_CHECK_HIP(hipGetDevice(&dev), "ensemble_bwd_fused");
+  if (dev >= 0 && dev < 64 && !opted[dev]) {
+    SERL_CHECK_HIP(hipFuncSetAttribute((const void*)ens_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, EB_LDS), "ensemble_bwd_fused");
+    opted[dev] = true;
+  }
+  EnsBwdArgs a{dq, hw, (long long)EH, h1, xh1, rs1, g1s, w1, (long long)EH * EH, h0, xh0, rs0, g0s, dz1, g1, dz0, g0, B, use_ln, EH, E};
+  hipLaunchKernelGGL(ens_bwd_kernel, dim3(ens_grid(E, B)), dim3(ENT), EB_LDS, (hipStream_t)stream, a);
+  SERL_CHECK_LAUNCH("ensemble_bwd_fused");
+  return SERL_OK;
+}
+
+// All batch-column sums of that backward in one launch: gradients of the head (d_hw (E,256), d_hb (E)), of both LayerNorms
+// (d_lnb*, d_lns*; use_ln only) and of both Dense biases (d_b*), member e at e * 256.  Fixed summation order.
+extern "C" int serl_ensemble_colsum(const float* dq, const float* h1, const float* g1, const float* xh1, const float* dz1,
+                                    const float* g0, const float* xh0, const float* dz0, int B, int E, int use_ln,
+                                    float* d_hw, float* d_hb, float* d_lnb1, float* d_lns1, float* d_b1, float* d_lnb0,
+                                    float* d_lns0, float* d_b0, void* stream) {
+  SERL_CHECK_ARG(dq && h1 && dz1 && dz0 && d_hw && d_hb && d_b1 && d_b0, "ensemble_colsum: null pointer");
+  SERL_CHECK_ARG(!use_ln || (g1 && xh1 && g0 && xh0 && d_lnb1 && d_lns1 && d_lnb0 && d_lns0), "ensemble_colsum: LayerNorm operands missing");
+  SERL_CHECK_ARG(B >= 1 && E >= 1, "ensemble_colsum: bad shape");
+  EnsColsumArgs a{dq, h1, g1, xh1, dz1, g0, xh0, dz0, d_hw, d_hb, d_lnb1, d_lns1, d_b1, d_lnb0, d_lns0, d_b0, B, use_ln};
+  hipLaunchKernelGGL(ens_colsum_kernel, dim3(E, 3, EH / CS_COLS), dim3(CS_RG * CS_COLS), 0, (hipStream_t)stream, a);
+  SERL_CHECK_LAUNCH("ensemble_colsum");
   return SERL_OK;
 }

@@ -812,3 +812,43 @@ def test_config2_utd20_two_buffers_matches_oracle(dev, prec):
         assert_info_close(info, oinfo, rtol=1e-3 if prec == "highest" else 5e-3)
         assert np.array_equal(agent.rng, ostate["rng"])
     _check_params(agent, ostate, 3e-4, 2 * U)
+
+
+@pytest.mark.parametrize("kind", ["state_ln", "state_plain", "pixel"])
+def test_fused_ensemble_backward_matches_unfused(dev, kind, monkeypatch):
+    """csrc/ensemble.hip ens_bwd_kernel + ens_colsum_kernel (the critic ensemble's backward in two launches) against the
+    launch-by-launch path (SERL_AMD_ENS_BWD_FUSED=0: ln_act_bwd, GEMM, ln_act_bwd, four column-sum launches): same bf16_3x
+    products, LayerNorm backward arithmetic and fixed-order sums, only the summation ORDER of the 256-term contraction and
+    of the batch-column sums differs -> every critic / actor gradient leaf within 2e-6 (pixel: 2e-5) of its scale after one step, at a
+    batch that is not a multiple of the kernel's 32-row blocks; the oracle parity tests of this file run the fused path."""
+    from serl_amd.agents import DrQLearner, SACLearner
+    rng = np.random.default_rng(5)
+    if kind == "pixel":
+        keys = ("wrist_1", "wrist_2")
+        obs_space, act_space = pixel_spaces(keys, 32, 32, 1, 19, 7)
+        mk = lambda: DrQLearner.create(5, obs_space, act_space, pixel_keys=keys, num_qs=10, num_min_qs=2,
+                                       critic_layer_norm=True, backup_entropy=False)
+        batch = make_pixel_batch(rng, 44, keys, 32, 32, 1, 19, 7, packed=True)
+        upd = lambda a: a.update(batch, 1, pixel_keys=keys)
+    else:
+        obs_space, act_space = state_spaces(17, 6)
+        ln = kind == "state_ln"
+        mk = lambda: SACLearner.create(5, obs_space, act_space, num_qs=10 if ln else 2, num_min_qs=2 if ln else None,
+                                       critic_layer_norm=ln)
+        batch = make_state_batch(rng, 150, 17, 6)
+        upd = lambda a: a.update(batch, 1)
+    out = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("SERL_AMD_ENS_BWD_FUSED", fused)        # read when the native handle is created
+        agent = mk()
+        new, info = upd(agent)
+        info = dict(info)
+        torch.cuda.synchronize()
+        out[fused] = ({n: agent._shared[n].numpy_tree() for n in ("critic_grads", "actor_grads")}, info)
+    # (pixel: the conv stack's backward amplifies the re-ordered sums; the actor step runs behind the critic's Adam step,
+    # whose sign-like first update turns them into +-lr differences of single weights)
+    assert_tree_close(out["1"][0]["critic_grads"], out["0"][0]["critic_grads"], rtol=2e-5 if kind == "pixel" else 2e-6, what="critic_grads")
+    assert_tree_close(out["1"][0]["actor_grads"], out["0"][0]["actor_grads"], rtol=2e-4, what="actor_grads")
+    for k in out["0"][1]:
+        a, b = out["1"][1][k], out["0"][1][k]
+        assert abs(a - b) <= 1e-5 * max(abs(b), 1e-2), (k, a, b)
