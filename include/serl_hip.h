@@ -232,6 +232,16 @@ int serl_ensemble_fwd_fused(const float* inp, int ld_inp, int din, int B, int E,
                             long long w1_member_stride, long long vec_member_stride, long long head_bias_member_stride,
                             int use_ln, float* h0, float* h1, float* xh0, float* xh1, float* rs0, float* rs1, float* q,
                             void* stream);
+/* TanhNormal(MLP(256, 256)) policy forward in ONE launch (csrc/ensemble.hip): Dense + ReLU twice, the two Dense heads,
+ * log-std clip, the jax.random.normal draw keyed by the global element index, a = tanh(mean + sigma eps) and log pi(a)
+ * (serl/distributions/tanh_normal.py:17-53 behind serl/networks/mlp.py:18-35; sampled at sac_learner.py:126,169 and
+ * serl/agents/agent.py:12-22) -- what three serl_gemm launches + serl_tanh_gaussian_fwd compute.  z (B, ld_z): the first
+ * din columns are the MLP input.  h0 / h1 (B, 256) post-ReLU activations, ms (B, 2A) raw [mean | log_std], eps (B, A),
+ * logp (B) may be NULL.  action_dim <= 8; precision "bf16_3x" only. */
+int serl_policy_fwd_fused(const float* z, int ld_z, int din, int B, const float* w0, const float* b0, const float* w1,
+                          const float* b1, const float* mk, const float* lk, const float* mb, const float* lb, int A,
+                          unsigned k0, unsigned k1, int row_offset, int total_rows, int deterministic, float* act,
+                          int ld_act, float* ms, float* eps, float* logp, float* h0, float* h1, void* stream);
 /* Backward of the same network for all E members of the critic (member e's leaves e members behind the pointers) from
  * dq (E, B) = dLoss/dq, in ONE launch (csrc/ensemble.hip): dz1 / dz0 = gradients w.r.t. the outputs of the second / first
  * Dense, g1 / g0 = gradients w.r.t. the LayerNorm outputs (use_ln only; NULL otherwise) -- what serl_ln_act_bwd (rank-1

@@ -169,6 +169,7 @@ struct serl_learner {
   bool timing = false, phases = false;
   int wg_main_layers = getenv("SERL_AMD_WG_MAIN_LAYERS") ? atoi(getenv("SERL_AMD_WG_MAIN_LAYERS")) : 1;   // A/B switch
   bool ens_fused = getenv("SERL_AMD_ENS_FUSED") == nullptr || strcmp(getenv("SERL_AMD_ENS_FUSED"), "0") != 0;   // A/B switch
+  bool pol_fused = getenv("SERL_AMD_POL_FUSED") == nullptr || strcmp(getenv("SERL_AMD_POL_FUSED"), "0") != 0;   // A/B switch
   bool ens_bwd_fused = getenv("SERL_AMD_ENS_BWD_FUSED") == nullptr || strcmp(getenv("SERL_AMD_ENS_BWD_FUSED"), "0") != 0;   // A/B switch
   bool fuse12 = getenv("SERL_AMD_CONV_FUSE12") == nullptr || strcmp(getenv("SERL_AMD_CONV_FUSE12"), "0") != 0;   // A/B switch
   std::vector<TimeRec> trecs;
@@ -826,6 +827,25 @@ int policy_fwd(serl_learner* h, char tag, const Store& s, const ActorOff& ao, co
                bool deterministic, bool save, bool want_logp, float* logp_out, float** logp_ret) {
   const Cfg& c = h->cfg;
   const int A = c.A;
+  if (act && h->pol_fused && c.nh == 2 && c.hid[0] == 256 && c.hid[1] == 256 && A <= 8 && serl_get_matmul_precision() == 1) {
+    // the whole pass in one launch (ensemble.hip, policy epilogue): three GEMM launches + the sample kernel less
+    float *h0 = nullptr, *h1 = nullptr, *eps = nullptr, *logp = nullptr;
+    if (save) {
+      WSF(ws, st, a0, (size_t)B * 256, "ph0_%c", tag); h0 = a0;
+      WSF(ws, st, a1, (size_t)B * 256, "ph1_%c", tag); h1 = a1;
+      WSF(ws, st, e, (size_t)B * A, "eps_%c", tag); eps = e;
+    }
+    WSF(ws, st, ms, (size_t)B * 2 * A, "ms_%c", tag);
+    if (want_logp) {
+      if (logp_out) logp = logp_out;
+      else { WSF(ws, st, l, (size_t)B, "logp_%c", tag); logp = l; }
+    }
+    DRV(serl_policy_fwd_fused(z, ldz, c.latent, B, s.at(ao.w[0]), s.at(ao.b[0]), s.at(ao.w[1]), s.at(ao.b[1]), s.at(ao.mk),
+                              s.at(ao.lk), s.at(ao.mb), s.at(ao.lb), A, key ? key[0] : 0, key ? key[1] : 0, row_offset,
+                              total_rows, deterministic, act, ld_act, ms, eps, logp, h0, h1, st));
+    if (logp_ret) *logp_ret = logp;
+    return SERL_OK;
+  }
   const float* a_ptr = z; long long a_ms = ldz; int din = c.latent;
   for (int i = 0; i < c.nh; ++i) {
     const int hd = c.hid[i];

@@ -206,13 +206,113 @@ __device__ __forceinline__ void ens_ln_rows(const float* Cs, int wid, int lane, 
   }
 }
 
+// ---- TanhNormal policy head behind the same two-layer MLP (serl/distributions/tanh_normal.py:17-53; MLP without
+// LayerNorm, activate_final): mean = h1 . mk + mb, log_std = clip(h1 . lk + lb, -20, 2), a = tanh(mean + sigma * eps) with
+// eps from the jax.random.normal stream at the GLOBAL element index, log pi(a) -- the arithmetic of a GEMM launch for the
+// two Dense heads + tanh_gaussian_fwd_kernel, here as the epilogue of the fused forward (POL = true): the policy pass was
+// four dependent launches (3 GEMMs + sample), 42 us of the state-based learner's 160 us step.
+constexpr int PA = 8;                     // most action dimensions the fused head takes
+struct PolHead {
+  const float *mk, *lk, *mb, *lb;         // (256, A) kernels, (A) biases
+  int A; uint32_t k0, k1; int row_offset, total_rows, deterministic;
+  float* act; int ld_act;                 // (B, A) actions, row stride ld_act
+  float* ms;                              // (B, 2A) raw [mean | log_std] (what the backward reads) or nullptr
+  float* eps; float* logp;                // (B, A) / (B) or nullptr
+};
+struct PolW { float m[4][PA], l[4][PA]; };
+__device__ __forceinline__ void pol_wload(const PolHead& ph, int lane, PolW& w) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < PA; ++j) {        // unconditional loads from a clamped column (columns >= A are never used)
+      const int at = (lane + 64 * i) * ph.A + min(j, ph.A - 1);
+      w.m[i][j] = ph.mk[at];
+      w.l[i][j] = ph.lk[at];
+    }
+}
+// rows [4 wid, 4 wid + 4): h1 = relu(acc + b1) (to HBM when hout), the 2A head dot products, sample + log-prob in lanes j < A
+__device__ __forceinline__ void pol_head_rows(const float* Cs, int wid, int lane, int row_base, int B, const float* bias,
+                                              float* hout, const PolHead& ph, const PolW& w) {
+  float bi[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) bi[i] = bias[lane + 64 * i];
+  float dm[ENR][PA], dl[ENR][PA];
+#pragma unroll
+  for (int rr = 0; rr < ENR; ++rr) {
+    const int row = wid * ENR + rr, grow = row_base + row;
+    float v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[i] = fmaxf(Cs[row * E_LDC + lane + 64 * i] + bi[i], 0.f);
+      if (hout && grow < B) hout[(long long)grow * EH + lane + 64 * i] = v[i];
+    }
+#pragma unroll
+    for (int j = 0; j < PA; ++j) {
+      float sm = 0.f, sl = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { sm = fmaf(v[i], w.m[i][j], sm); sl = fmaf(v[i], w.l[i][j], sl); }
+      dm[rr][j] = sm; dl[rr][j] = sl;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+    for (int rr = 0; rr < ENR; ++rr)
+#pragma unroll
+      for (int j = 0; j < PA; ++j) {
+        dm[rr][j] += __shfl_xor(dm[rr][j], o);
+        dl[rr][j] += __shfl_xor(dl[rr][j], o);
+      }
+  const int A = ph.A, jl = min(lane, A - 1);
+  const float mb = ph.mb[jl], lb = ph.lb[jl];
+  float lp[ENR];
+#pragma unroll
+  for (int rr = 0; rr < ENR; ++rr) {
+    const int grow = row_base + wid * ENR + rr;
+    float mu = 0.f, raw = 0.f;
+#pragma unroll
+    for (int j = 0; j < PA; ++j) {
+      mu = lane == j ? dm[rr][j] : mu;
+      raw = lane == j ? dl[rr][j] : raw;
+    }
+    mu += mb; raw += lb;
+    const bool on = lane < A && grow < B;
+    const float ls = fminf(fmaxf(raw, -20.f), 2.f);
+    float e = 0.f;
+    if (!ph.deterministic) {
+      const uint32_t idx = (uint32_t)(ph.row_offset + min(grow, B - 1)) * (uint32_t)A + (uint32_t)jl;
+      e = jax_normal_from_bits(threefry_bits_at(ph.k0, ph.k1, idx, (uint32_t)ph.total_rows * (uint32_t)A));
+    }
+    const float x = mu + expf(ls) * e;
+    const float z = (x - mu) * expf(-ls);
+    const float term = (-0.5f * z * z - ls - 0.918938533204672742f) - 2.f * (0.693147180559945309f - x - softplusf(-2.f * x));
+    lp[rr] = on ? term : 0.f;
+    if (on) {
+      ph.act[(long long)grow * ph.ld_act + lane] = tanhf(x);
+      if (ph.ms) { ph.ms[(long long)grow * 2 * A + lane] = mu; ph.ms[(long long)grow * 2 * A + A + lane] = raw; }
+      if (ph.eps) ph.eps[(long long)grow * A + lane] = e;
+    }
+  }
+  if (ph.logp) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1)       // lanes 0 .. A - 1 <= 7 hold the terms
+#pragma unroll
+      for (int rr = 0; rr < ENR; ++rr) lp[rr] += __shfl_xor(lp[rr], o);
+#pragma unroll
+    for (int rr = 0; rr < ENR; ++rr) {
+      const int grow = row_base + wid * ENR + rr;
+      if (lane == 0 && grow < B) ph.logp[grow] = lp[rr];
+    }
+  }
+}
+
 // K slabs of both layers form ONE sequence s = 0 .. n1 + 7 (n1 = ceil(din / 32) slabs of layer 1, then the 8 of layer 2)
 // that runs through a ring of four register sets and two LDS buffers: in step s the block multiplies slab s from LDS
 // buffer s & 1, writes slab s + 1 (loaded four steps ago) into the other buffer and requests slab s + 5 -- one barrier per
 // step, and four steps (~4 us) for a load to land: the blocks are few (E x B / 32) and each walks its K loop alone on its
 // CU, so the memory round trip of a step is not hidden by anybody else.  R = n1 % 4 makes every ring index static.
-template <int R>
-__global__ __launch_bounds__(ENT, 1) void ens_fwd_kernel(const EnsFwdArgs a) {
+template <int R, bool POL>
+__global__ __launch_bounds__(ENT, 1) void ens_fwd_kernel(const EnsFwdArgs a, const PolHead ph) {
   extern __shared__ __attribute__((aligned(16))) uint32_t e_smem[];
   uint32_t* const Xs = e_smem;                       // [buf][hi, lo][32][E_LDKW_X]
   uint32_t* const Ws = Xs + 4 * E_XPART;             // [buf][hi, lo][16][E_LDW]
@@ -296,6 +396,11 @@ __global__ __launch_bounds__(ENT, 1) void ens_fwd_kernel(const EnsFwdArgs a) {
               nullptr, nullptr, nullptr);
 #pragma unroll
   for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+  PolW pw;
+  if constexpr (POL) {                                // the head kernels: requested here, used behind layer 2
+    pol_wload(ph, lane, pw);
+    __builtin_amdgcn_sched_barrier(0);
+  }
   __syncthreads();                                    // the h0 image is complete
   // ---- layer 2: K = 256, A operand resident in LDS; ring position of its slab t is (R + t) % 4
   auto step2 = [&](auto u_tag, auto next_tag, int t) {
@@ -315,9 +420,13 @@ __global__ __launch_bounds__(ENT, 1) void ens_fwd_kernel(const EnsFwdArgs a) {
   if constexpr (R == 3) run2(T3, T0, T1, T2);
   ens_acc_to_tile(Cs, wid, r, h, acc);
   __syncthreads();
-  ens_ln_rows(Cs, wid, lane, row_base, a.B, a.b1 + vo, a.use_ln ? a.g1 + vo : nullptr, a.use_ln ? a.be1 + vo : nullptr,
-              a.use_ln, a.width, a.h1 ? a.h1 + ro * EH : nullptr, a.xh1 ? a.xh1 + ro * EH : nullptr, a.rs1 ? a.rs1 + ro : nullptr,
-              nullptr, a.hw + vo, a.hb + e * a.hb_ms, a.q + ro);
+  if constexpr (POL) {
+    pol_head_rows(Cs, wid, lane, row_base, a.B, a.b1, a.h1, ph, pw);
+  } else {
+    ens_ln_rows(Cs, wid, lane, row_base, a.B, a.b1 + vo, a.use_ln ? a.g1 + vo : nullptr, a.use_ln ? a.be1 + vo : nullptr,
+                a.use_ln, a.width, a.h1 ? a.h1 + ro * EH : nullptr, a.xh1 ? a.xh1 + ro * EH : nullptr, a.rs1 ? a.rs1 + ro : nullptr,
+                nullptr, a.hw + vo, a.hb + e * a.hb_ms, a.q + ro);
+  }
 }
 
 
@@ -570,6 +679,31 @@ __global__ __launch_bounds__(CS_RG * CS_COLS) void ens_colsum_kernel(const EnsCo
   }
 }
 
+template <bool POL>
+static int ens_fwd_launch(const EnsFwdArgs& a, const PolHead& ph, int E, const char* name, void* stream) {
+  static_assert(E_LDS <= 160 * 1024, "LDS");
+  static bool opted[64] = {};
+  int dev = 0;
+  SERL_CHECK_HIP(hipGetDevice(&dev), name);
+  if (dev >= 0 && dev < 64 && !opted[dev]) {
+    const void* ks[4] = {(const void*)ens_fwd_kernel<0, POL>, (const void*)ens_fwd_kernel<1, POL>, (const void*)ens_fwd_kernel<2, POL>,
+                         (const void*)ens_fwd_kernel<3, POL>};
+    for (const void* k : ks)
+      SERL_CHECK_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, E_LDS), name);
+    opted[dev] = true;
+  }
+  const dim3 grid(cdiv(a.B, EBM), E);
+  hipStream_t st = (hipStream_t)stream;
+  switch (cdiv(a.din, EBK) % 4) {
+    case 0: hipLaunchKernelGGL((ens_fwd_kernel<0, POL>), grid, dim3(ENT), E_LDS, st, a, ph); break;
+    case 1: hipLaunchKernelGGL((ens_fwd_kernel<1, POL>), grid, dim3(ENT), E_LDS, st, a, ph); break;
+    case 2: hipLaunchKernelGGL((ens_fwd_kernel<2, POL>), grid, dim3(ENT), E_LDS, st, a, ph); break;
+    default: hipLaunchKernelGGL((ens_fwd_kernel<3, POL>), grid, dim3(ENT), E_LDS, st, a, ph); break;
+  }
+  SERL_CHECK_LAUNCH(name);
+  return SERL_OK;
+}
+
 }  // namespace
 
 // E members (member e at the given strides from the pointers of the first one) on a shared input inp (B, ld_inp) whose
@@ -586,29 +720,28 @@ extern "C" int serl_ensemble_fwd_fused(const float* inp, int ld_inp, int din, in
   SERL_CHECK_ARG(serl_get_matmul_precision() == 1, "ensemble_fwd_fused: bf16_3x precision only");
   SERL_CHECK_ARG(((uintptr_t)w0 & 15) == 0 && ((uintptr_t)w1 & 15) == 0 && w0_member_stride % 4 == 0 && w1_member_stride % 4 == 0,
                  "ensemble_fwd_fused: kernels must be 16-byte aligned");
-  static_assert(E_LDS <= 160 * 1024, "LDS");
-  static bool opted[64] = {};
-  int dev = 0;
-  SERL_CHECK_HIP(hipGetDevice(&dev), "ensemble_fwd_fused");
-  if (dev >= 0 && dev < 64 && !opted[dev]) {
-    const void* ks[4] = {(const void*)ens_fwd_kernel<0>, (const void*)ens_fwd_kernel<1>, (const void*)ens_fwd_kernel<2>,
-                         (const void*)ens_fwd_kernel<3>};
-    for (const void* k : ks)
-      SERL_CHECK_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, E_LDS), "ensemble_fwd_fused");
-    opted[dev] = true;
-  }
   EnsFwdArgs a{inp, ld_inp, din, B, E, w0, b0, g0, be0, w1, b1, g1, be1, hw, hb, w0_member_stride, w1_member_stride,
                vec_member_stride, head_bias_member_stride, use_ln, EH, h0, h1, xh0, xh1, rs0, rs1, q};
-  const dim3 grid(cdiv(B, EBM), E);
-  hipStream_t st = (hipStream_t)stream;
-  switch (cdiv(din, EBK) % 4) {
-    case 0: hipLaunchKernelGGL(ens_fwd_kernel<0>, grid, dim3(ENT), E_LDS, st, a); break;
-    case 1: hipLaunchKernelGGL(ens_fwd_kernel<1>, grid, dim3(ENT), E_LDS, st, a); break;
-    case 2: hipLaunchKernelGGL(ens_fwd_kernel<2>, grid, dim3(ENT), E_LDS, st, a); break;
-    default: hipLaunchKernelGGL(ens_fwd_kernel<3>, grid, dim3(ENT), E_LDS, st, a); break;
-  }
-  SERL_CHECK_LAUNCH("ensemble_fwd_fused");
-  return SERL_OK;
+  return ens_fwd_launch<false>(a, PolHead{}, E, "ensemble_fwd_fused", stream);
+}
+
+// TanhNormal(MLP(256, 256)) policy forward in ONE launch (POL epilogue above): z (B, ld_z) whose first din columns are the
+// MLP input.  h0 / h1 (B, 256): post-ReLU activations for the backward, or NULL; ms (B, 2A) raw [mean | log_std], eps (B, A),
+// logp (B): may be NULL.  key NULL-equivalent: deterministic != 0 -> a = tanh(mean).  "bf16_3x" only, action_dim <= 8.
+extern "C" int serl_policy_fwd_fused(const float* z, int ld_z, int din, int B, const float* w0, const float* b0,
+                                     const float* w1, const float* b1, const float* mk, const float* lk, const float* mb,
+                                     const float* lb, int A, unsigned k0, unsigned k1, int row_offset, int total_rows,
+                                     int deterministic, float* act, int ld_act, float* ms, float* eps, float* logp,
+                                     float* h0, float* h1, void* stream) {
+  SERL_CHECK_ARG(z && w0 && b0 && w1 && b1 && mk && lk && mb && lb && act, "policy_fwd_fused: null pointer");
+  SERL_CHECK_ARG(B >= 1 && din >= 1 && ld_z >= din && A >= 1 && A <= PA && ld_act >= A, "policy_fwd_fused: bad shape (action_dim <= %d)", PA);
+  SERL_CHECK_ARG(row_offset >= 0 && row_offset + B <= total_rows, "policy_fwd_fused: shard outside the global batch");
+  SERL_CHECK_ARG(serl_get_matmul_precision() == 1, "policy_fwd_fused: bf16_3x precision only");
+  SERL_CHECK_ARG(((uintptr_t)w0 & 15) == 0 && ((uintptr_t)w1 & 15) == 0, "policy_fwd_fused: kernels must be 16-byte aligned");
+  EnsFwdArgs a{z, ld_z, din, B, 1, w0, b0, nullptr, nullptr, w1, b1, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, EH,
+               h0, h1, nullptr, nullptr, nullptr, nullptr, nullptr};
+  PolHead ph{mk, lk, mb, lb, A, k0, k1, row_offset, total_rows, deterministic, act, ld_act, ms, eps, logp};
+  return ens_fwd_launch<true>(a, ph, 1, "policy_fwd_fused", stream);
 }
 
 // Backward of serl_ensemble_fwd_fused's network for ALL E members (member stride = one member, the critic's own layout) from

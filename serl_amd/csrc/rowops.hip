@@ -449,35 +449,7 @@ extern "C" int serl_fill(float* p, float v, long long n, void* stream) {
 }
 
 // ------------------------------------------------------------------ tanh-Gaussian policy head
-// XLA's float32 erf_inv (Giles); jax.random.normal = sqrt(2) * erf_inv(uniform(nextafter(-1,0), 1)).
-// Every step is a separately rounded fp32 operation (__fmul_rn / __fadd_rn: no FMA contraction), the evaluation XLA's
-// HLO expansion of erf_inv describes and the oracle (oracle/prng.py erfinv_f32) restates op by op, so the normal draws
-// agree with the oracle up to the last-place differences of log1pf / sqrtf.
-__device__ __forceinline__ float erfinv_f32(float x) {
-  float w = -log1pf(-__fmul_rn(x, x));
-  float p;
-#define EI(c) p = __fadd_rn(c, __fmul_rn(p, w));
-  if (w < 5.0f) {
-    w = __fadd_rn(w, -2.5f);
-    p = 2.81022636e-08f;
-    EI(3.43273939e-07f) EI(-3.5233877e-06f) EI(-4.39150654e-06f) EI(0.00021858087f) EI(-0.00125372503f)
-    EI(-0.00417768164f) EI(0.246640727f) EI(1.50140941f)
-  } else {
-    w = __fadd_rn(sqrtf(w), -3.0f);
-    p = -0.000200214257f;
-    EI(0.000100950558f) EI(0.00134934322f) EI(-0.00367342844f) EI(0.00573950773f) EI(-0.0076224613f)
-    EI(0.00943887047f) EI(1.00167406f) EI(2.83297682f)
-  }
-#undef EI
-  return fabsf(x) == 1.0f ? copysignf(INFINITY, x) : __fmul_rn(p, x);
-}
-__device__ __forceinline__ float jax_normal_from_bits(uint32_t bits) {
-  const float lo = -0.99999994f;  // nextafter(-1, 0)
-  const float u01 = __uint_as_float((bits >> 9) | 0x3F800000u) - 1.0f;
-  const float u = fmaxf(lo, __fadd_rn(__fmul_rn(u01, __fadd_rn(1.0f, -lo)), lo));
-  return __fmul_rn(1.41421356237309515f, erfinv_f32(u));
-}
-__device__ __forceinline__ float softplusf(float x) { return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x))); }
+// (erfinv_f32, jax_normal_from_bits, softplusf: common.h -- shared with the fused policy forward of ensemble.hip)
 
 // One thread per row.  mean / log_std_raw: (B, A) with row stride ld_ms (the two Dense heads write
 // side by side).  a = tanh(mean + exp(clip(log_std)) * eps); log pi(a) as TFP computes it from the

@@ -852,3 +852,41 @@ def test_fused_ensemble_backward_matches_unfused(dev, kind, monkeypatch):
     for k in out["0"][1]:
         a, b = out["1"][1][k], out["0"][1][k]
         assert abs(a - b) <= 1e-5 * max(abs(b), 1e-2), (k, a, b)
+
+
+@pytest.mark.parametrize("kind", ["state", "pixel"])
+def test_fused_policy_forward_matches_unfused(dev, kind, monkeypatch):
+    """csrc/ensemble.hip, policy epilogue (TanhNormal(MLP) forward in one launch: Dense + ReLU twice with the bf16_3x MFMA
+    products of the GEMM launches, the two Dense heads as fp32 dot products, jax.random.normal at the global element index,
+    tanh, log-prob) against the four launches it replaces (SERL_AMD_POL_FUSED=0): sampled and mode actions within 2e-5,
+    the rng bit-identical, one update's logged scalars within 1e-4 -- at a batch that is not a multiple of 32 rows."""
+    from serl_amd.agents import DrQLearner, SACLearner
+    rng = np.random.default_rng(6)
+    if kind == "pixel":
+        keys = ("wrist_1", "wrist_2")
+        obs_space, act_space = pixel_spaces(keys, 32, 32, 1, 19, 7)
+        mk = lambda: DrQLearner.create(7, obs_space, act_space, pixel_keys=keys, num_qs=4, num_min_qs=2,
+                                       critic_layer_norm=True, backup_entropy=True)
+        batch = make_pixel_batch(rng, 2 * 21, keys, 32, 32, 1, 19, 7, packed=True)
+        upd = lambda a: a.update(batch, 2, pixel_keys=keys)
+        ob = {k: rng.integers(0, 256, size=(32, 32, 3, 1), dtype=np.uint8) for k in keys}
+        ob["state"] = rng.standard_normal(19).astype(np.float32)
+    else:
+        obs_space, act_space = state_spaces(17, 6)
+        mk = lambda: SACLearner.create(7, obs_space, act_space, num_qs=2, backup_entropy=True)
+        batch = make_state_batch(rng, 3 * 50, 17, 6)
+        upd = lambda a: a.update(batch, 3)
+        ob = rng.standard_normal(17).astype(np.float32)
+    out = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("SERL_AMD_POL_FUSED", fused)        # read when the native handle is created
+        agent = mk()
+        a, agent2 = agent.sample_actions(ob)
+        m = agent.eval_actions(ob)
+        new, info = upd(agent)
+        out[fused] = (a, m, agent2.rng, dict(info), new.rng)
+    assert np.abs(out["1"][0] - out["0"][0]).max() <= 2e-5 and np.abs(out["1"][1] - out["0"][1]).max() <= 2e-5
+    assert np.array_equal(out["1"][2], out["0"][2]) and np.array_equal(out["1"][4], out["0"][4])
+    for k in out["0"][3]:
+        a, b = out["1"][3][k], out["0"][3][k]
+        assert abs(a - b) <= 1e-4 * max(abs(b), 1e-2), (k, a, b)
