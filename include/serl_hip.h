@@ -232,6 +232,18 @@ int serl_ensemble_fwd_fused(const float* inp, int ld_inp, int din, int B, int E,
                             long long w1_member_stride, long long vec_member_stride, long long head_bias_member_stride,
                             int use_ln, float* h0, float* h1, float* xh0, float* xh1, float* rs0, float* rs1, float* q,
                             void* stream);
+/* Two serl_ensemble_fwd_fused problems of the same batch size and input width in ONE launch -- the state-based learners'
+ * target pass (REDQ-subsampled members, next observations) and critic pass (all members, observations) of
+ * sac_learner.py:177-206, both on the caller's stream.  Fields as the arguments of serl_ensemble_fwd_fused; bit-identical
+ * to two calls of it. */
+typedef struct {
+  const float* inp; int ld_inp, din, B, E;
+  const float *w0, *b0, *g0, *be0, *w1, *b1, *g1, *be1, *hw, *hb;
+  long long w0_member_stride, w1_member_stride, vec_member_stride, head_bias_member_stride;
+  int use_ln;
+  float *h0, *h1, *xh0, *xh1, *rs0, *rs1, *q;
+} serl_ens_fwd_job;
+int serl_ensemble_fwd_fused_pair(const serl_ens_fwd_job* a, const serl_ens_fwd_job* b, void* stream);
 /* TanhNormal(MLP(256, 256)) policy forward in ONE launch (csrc/ensemble.hip): Dense + ReLU twice, the two Dense heads,
  * log-std clip, the jax.random.normal draw keyed by the global element index, a = tanh(mean + sigma eps) and log pi(a)
  * (serl/distributions/tanh_normal.py:17-53 behind serl/networks/mlp.py:18-35; sampled at sac_learner.py:126,169 and

@@ -602,6 +602,39 @@ int critic_dropout(const Cfg& c, const uint32_t* key, int layer, float* x, int E
   return SERL_OK;
 }
 
+bool ens_fwd_fusable(const serl_learner* h) {
+  const Cfg& c = h->cfg;
+  return h->ens_fused && c.nh == 2 && c.hid[0] == 256 && c.hid[1] == 256 && serl_get_matmul_precision() == 1;
+}
+// arguments (and workspace buffers) of one fused ensemble forward: members m0, m0 + mstride, ... (E of them)
+int ens_fwd_job(serl_learner* h, char tag, const Store& s, const CriticOff& co, int m0, int mstride, int E, const float* inp,
+                int ld_inp, int B, Workspace& ws, hipStream_t st, bool save, serl_ens_fwd_job* j) {
+  const Cfg& c = h->cfg;
+  const int din = c.latent + c.crit_A;
+  const long long v = 256;
+  WSF(ws, st, q, (size_t)E * B, "q_%c", tag);
+  float *h0 = nullptr, *h1 = nullptr, *xh0 = nullptr, *xh1 = nullptr, *rs0 = nullptr, *rs1 = nullptr;
+  if (save) {
+    WSF(ws, st, a0, (size_t)E * B * 256, "h0_%c", tag); h0 = a0;
+    WSF(ws, st, a1, (size_t)E * B * 256, "h1_%c", tag); h1 = a1;
+    if (c.ln) {
+      WSF(ws, st, x0, (size_t)E * B * 256, "exh0_%c", tag); xh0 = x0;
+      WSF(ws, st, x1, (size_t)E * B * 256, "exh1_%c", tag); xh1 = x1;
+      WSF(ws, st, r0, (size_t)E * B, "ers0_%c", tag); rs0 = r0;
+      WSF(ws, st, r1, (size_t)E * B, "ers1_%c", tag); rs1 = r1;
+    }
+  }
+  *j = serl_ens_fwd_job{inp, ld_inp, din, B, E,
+                        s.at(co.w[0]) + (long long)m0 * din * 256, s.at(co.b[0]) + m0 * v,
+                        c.ln ? s.at(co.lns[0]) + m0 * v : nullptr, c.ln ? s.at(co.lnb[0]) + m0 * v : nullptr,
+                        s.at(co.w[1]) + (long long)m0 * 256 * 256, s.at(co.b[1]) + m0 * v,
+                        c.ln ? s.at(co.lns[1]) + m0 * v : nullptr, c.ln ? s.at(co.lnb[1]) + m0 * v : nullptr,
+                        s.at(co.hk) + (long long)m0 * 256, s.at(co.hb) + m0,
+                        (long long)mstride * din * 256, (long long)mstride * 256 * 256, mstride * v, (long long)mstride,
+                        c.ln, h0, h1, xh0, xh1, rs0, rs1, q};
+  return SERL_OK;
+}
+
 // drop: rngs={"dropout": key} of a training=True apply (used only with critic_dropout_rate > 0); row0 / total: global row
 // of this rank's row 0 and the global minibatch size
 int ensemble_fwd(serl_learner* h, char tag, const Store& s, const CriticOff& co, int m0, int mstride, int E,
@@ -615,27 +648,14 @@ int ensemble_fwd(serl_learner* h, char tag, const Store& s, const CriticOff& co,
   WSF(ws, st, q, (size_t)E * B, "q_%c", tag);
   const float* head_w = s.at(co.hk) + (long long)m0 * hl;
   const float* head_b = s.at(co.hb) + m0;
-  if (!drop && h->ens_fused && nl == 2 && c.hid[0] == 256 && c.hid[1] == 256 && serl_get_matmul_precision() == 1) {
+  if (!drop && ens_fwd_fusable(h)) {
     // the whole pass in one launch (ensemble.hip): four dependent launches less on a latency-bound chain
-    float *h0 = nullptr, *h1 = nullptr, *xh0 = nullptr, *xh1 = nullptr, *rs0 = nullptr, *rs1 = nullptr;
-    if (save) {
-      WSF(ws, st, a0, (size_t)E * B * 256, "h0_%c", tag); h0 = a0;
-      WSF(ws, st, a1, (size_t)E * B * 256, "h1_%c", tag); h1 = a1;
-      if (c.ln) {
-        WSF(ws, st, x0, (size_t)E * B * 256, "exh0_%c", tag); xh0 = x0;
-        WSF(ws, st, x1, (size_t)E * B * 256, "exh1_%c", tag); xh1 = x1;
-        WSF(ws, st, r0, (size_t)E * B, "ers0_%c", tag); rs0 = r0;
-        WSF(ws, st, r1, (size_t)E * B, "ers1_%c", tag); rs1 = r1;
-      }
-    }
-    const long long v = 256;
-    DRV(serl_ensemble_fwd_fused(inp, ld_inp, din, B, E, s.at(co.w[0]) + (long long)m0 * din * 256, s.at(co.b[0]) + m0 * v,
-                                c.ln ? s.at(co.lns[0]) + m0 * v : nullptr, c.ln ? s.at(co.lnb[0]) + m0 * v : nullptr,
-                                s.at(co.w[1]) + (long long)m0 * 256 * 256, s.at(co.b[1]) + m0 * v,
-                                c.ln ? s.at(co.lns[1]) + m0 * v : nullptr, c.ln ? s.at(co.lnb[1]) + m0 * v : nullptr, head_w,
-                                head_b, (long long)mstride * din * 256, (long long)mstride * 256 * 256, mstride * v, mstride,
-                                c.ln, h0, h1, xh0, xh1, rs0, rs1, q, st));
-    *q_out = q;
+    serl_ens_fwd_job j;
+    DRV(ens_fwd_job(h, tag, s, co, m0, mstride, E, inp, ld_inp, B, ws, st, save, &j));
+    DRV(serl_ensemble_fwd_fused(j.inp, j.ld_inp, j.din, j.B, j.E, j.w0, j.b0, j.g0, j.be0, j.w1, j.b1, j.g1, j.be1, j.hw, j.hb,
+                                j.w0_member_stride, j.w1_member_stride, j.vec_member_stride, j.head_bias_member_stride,
+                                j.use_ln, j.h0, j.h1, j.xh0, j.xh1, j.rs0, j.rs1, j.q, st));
+    *q_out = j.q;
     return SERL_OK;
   }
   for (int i = 0; i < nl; ++i) {
@@ -1446,9 +1466,18 @@ extern "C" int serl_learner_update(serl_learner* h, const serl_agent_buffers* ag
     else DRV(enqueue_actor_obs());
     if (sta != st) DRV_HIP(hipStreamWaitEvent(st, h->adone[i], 0));
     float *next_q, *q;
-    DRV(ensemble_fwd(h, 'T', tstore, co, m0, mstride, emin, zT, ldz, B, ws, st, false, &next_q, &step_keys[8 * i + 4], rank * B, Bg));
-    if (c.pixel) DRV(serl_copy2d(zC + c.latent, ldz, bt->actions + (size_t)lo * A, A, B, A, s1));
-    DRV(ensemble_fwd(h, 'C', critic, co, 0, 1, E, zC, ldz, B, ws, s1, true, &q, &step_keys[8 * i + 6], rank * B, Bg));
+    if (!multi && c.crit_drop <= 0.f && ens_fwd_fusable(h)) {
+      // state-based learners: target and critic passes share the caller's stream -> one launch for both
+      serl_ens_fwd_job jt, jc;
+      DRV(ens_fwd_job(h, 'T', tstore, co, m0, mstride, emin, zT, ldz, B, ws, st, false, &jt));
+      DRV(ens_fwd_job(h, 'C', critic, co, 0, 1, E, zC, ldz, B, ws, st, true, &jc));
+      DRV(serl_ensemble_fwd_fused_pair(&jt, &jc, st));
+      next_q = jt.q; q = jc.q;
+    } else {
+      DRV(ensemble_fwd(h, 'T', tstore, co, m0, mstride, emin, zT, ldz, B, ws, st, false, &next_q, &step_keys[8 * i + 4], rank * B, Bg));
+      if (c.pixel) DRV(serl_copy2d(zC + c.latent, ldz, bt->actions + (size_t)lo * A, A, B, A, s1));
+      DRV(ensemble_fwd(h, 'C', critic, co, 0, 1, E, zC, ldz, B, ws, s1, true, &q, &step_keys[8 * i + 6], rank * B, Bg));
+    }
     DRV(link(s1, st, h->join1));
     DRV(serl_td_loss(next_q, emin, bt->rewards + lo, bt->masks + lo, c.backup_entropy ? nlogp_all + (size_t)i * B : nullptr,
                      log_temp, c.discount, q, E, B, 1.0f / ((float)E * Bg), target_q, dq, info, st));

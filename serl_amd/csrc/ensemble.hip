@@ -10,6 +10,7 @@
 //   acc2 = h0 . W1[e];  h1 = relu(LN(acc2 + b1));  q = h1 . hw[e] + hb[e]
 // Same products, same k order, same LayerNorm / head reductions as the unfused launches: bit-identical results.
 // Precision "bf16_3x" only (the driver keeps the layer-by-layer path at "highest").
+#include "../../include/serl_hip.h"
 #include "igemm_bf3.h"
 
 #define ENS_LN_EPS 1e-6f   // flax.linen.LayerNorm default
@@ -312,15 +313,12 @@ __device__ __forceinline__ void pol_head_rows(const float* Cs, int wid, int lane
 // step, and four steps (~4 us) for a load to land: the blocks are few (E x B / 32) and each walks its K loop alone on its
 // CU, so the memory round trip of a step is not hidden by anybody else.  R = n1 % 4 makes every ring index static.
 template <int R, bool POL>
-__global__ __launch_bounds__(ENT, 1) void ens_fwd_kernel(const EnsFwdArgs a, const PolHead ph) {
+__device__ __forceinline__ void ens_fwd_body(const EnsFwdArgs& a, const PolHead& ph, const int e, const int row_base) {
   extern __shared__ __attribute__((aligned(16))) uint32_t e_smem[];
   uint32_t* const Xs = e_smem;                       // [buf][hi, lo][32][E_LDKW_X]
   uint32_t* const Ws = Xs + 4 * E_XPART;             // [buf][hi, lo][16][E_LDW]
   uint32_t* const Hs = Ws + 4 * E_WPART;             // [hi, lo][32][E_LDKW_H]
   float* const Cs = reinterpret_cast<float*>(Hs + 2 * E_HPART);
-  // (plain grid: the ring below already spreads a block's weight fetch over its whole run time; the XCD-aware map of the
-  // backward kernel measured 1 us SLOWER here -- 16 blocks of two members share one XCD's L2 ports)
-  const int e = blockIdx.y, row_base = blockIdx.x * EBM;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const float* w0 = a.w0 + e * a.w0_ms;
@@ -679,6 +677,21 @@ __global__ __launch_bounds__(CS_RG * CS_COLS) void ens_colsum_kernel(const EnsCo
   }
 }
 
+// (plain (row block, member) grid: the ring already spreads a block's weight fetch over its whole run time; the XCD-aware
+// map of the backward kernel measured 1 us SLOWER here -- 16 blocks of two members share one XCD's L2 ports)
+template <int R, bool POL>
+__global__ __launch_bounds__(ENT, 1) void ens_fwd_kernel(const EnsFwdArgs a, const PolHead ph) {
+  ens_fwd_body<R, POL>(a, ph, blockIdx.y, blockIdx.x * EBM);
+}
+// Two independent ensemble forwards of the same input width in ONE launch (the state-based learners' target and critic
+// passes, both on the caller's stream: a launch less on their latency-bound chain): members [0, a.E) of `a`, then `b`'s.
+template <int R>
+__global__ __launch_bounds__(ENT, 1) void ens_fwd2_kernel(const EnsFwdArgs a, const EnsFwdArgs b) {
+  const int y = blockIdx.y;
+  if (y < a.E) ens_fwd_body<R, false>(a, PolHead{}, y, blockIdx.x * EBM);
+  else ens_fwd_body<R, false>(b, PolHead{}, y - a.E, blockIdx.x * EBM);
+}
+
 template <bool POL>
 static int ens_fwd_launch(const EnsFwdArgs& a, const PolHead& ph, int E, const char* name, void* stream) {
   static_assert(E_LDS <= 160 * 1024, "LDS");
@@ -782,5 +795,45 @@ extern "C" int serl_ensemble_colsum(const float* dq, const float* h1, const floa
   EnsColsumArgs a{dq, h1, g1, xh1, dz1, g0, xh0, dz0, d_hw, d_hb, d_lnb1, d_lns1, d_b1, d_lnb0, d_lns0, d_b0, B, use_ln};
   hipLaunchKernelGGL(ens_colsum_kernel, dim3(E, 3, EH / CS_COLS), dim3(CS_RG * CS_COLS), 0, (hipStream_t)stream, a);
   SERL_CHECK_LAUNCH("ensemble_colsum");
+  return SERL_OK;
+}
+
+// Two ensemble forwards (same batch size, same input width) in one launch: see ens_fwd2_kernel.
+static int ens_job_args(const serl_ens_fwd_job* j, EnsFwdArgs& a, const char* name) {
+  SERL_CHECK_ARG(j && j->inp && j->w0 && j->b0 && j->w1 && j->b1 && j->hw && j->hb && j->q, "%s: null pointer", name);
+  SERL_CHECK_ARG(j->B >= 1 && j->E >= 1 && j->din >= 1 && j->ld_inp >= j->din, "%s: bad shape", name);
+  SERL_CHECK_ARG(!j->use_ln || (j->g0 && j->be0 && j->g1 && j->be1), "%s: LayerNorm needs scale and bias", name);
+  SERL_CHECK_ARG(((uintptr_t)j->w0 & 15) == 0 && ((uintptr_t)j->w1 & 15) == 0 && j->w0_member_stride % 4 == 0 &&
+                 j->w1_member_stride % 4 == 0, "%s: kernels must be 16-byte aligned", name);
+  a = EnsFwdArgs{j->inp, j->ld_inp, j->din, j->B, j->E, j->w0, j->b0, j->g0, j->be0, j->w1, j->b1, j->g1, j->be1, j->hw, j->hb,
+                 j->w0_member_stride, j->w1_member_stride, j->vec_member_stride, j->head_bias_member_stride, j->use_ln, EH,
+                 j->h0, j->h1, j->xh0, j->xh1, j->rs0, j->rs1, j->q};
+  return SERL_OK;
+}
+extern "C" int serl_ensemble_fwd_fused_pair(const serl_ens_fwd_job* ja, const serl_ens_fwd_job* jb, void* stream) {
+  EnsFwdArgs a, b;
+  if (int e = ens_job_args(ja, a, "ensemble_fwd_fused_pair")) return e;
+  if (int e = ens_job_args(jb, b, "ensemble_fwd_fused_pair")) return e;
+  SERL_CHECK_ARG(a.B == b.B && a.din == b.din, "ensemble_fwd_fused_pair: the two jobs must share batch size and input width");
+  SERL_CHECK_ARG(serl_get_matmul_precision() == 1, "ensemble_fwd_fused_pair: bf16_3x precision only");
+  static bool opted[64] = {};
+  int dev = 0;
+  SERL_CHECK_HIP(hipGetDevice(&dev), "ensemble_fwd_fused_pair");
+  if (dev >= 0 && dev < 64 && !opted[dev]) {
+    const void* ks[4] = {(const void*)ens_fwd2_kernel<0>, (const void*)ens_fwd2_kernel<1>, (const void*)ens_fwd2_kernel<2>,
+                         (const void*)ens_fwd2_kernel<3>};
+    for (const void* k : ks)
+      SERL_CHECK_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, E_LDS), "ensemble_fwd_fused_pair");
+    opted[dev] = true;
+  }
+  const dim3 grid(cdiv(a.B, EBM), a.E + b.E);
+  hipStream_t st = (hipStream_t)stream;
+  switch (cdiv(a.din, EBK) % 4) {
+    case 0: hipLaunchKernelGGL(ens_fwd2_kernel<0>, grid, dim3(ENT), E_LDS, st, a, b); break;
+    case 1: hipLaunchKernelGGL(ens_fwd2_kernel<1>, grid, dim3(ENT), E_LDS, st, a, b); break;
+    case 2: hipLaunchKernelGGL(ens_fwd2_kernel<2>, grid, dim3(ENT), E_LDS, st, a, b); break;
+    default: hipLaunchKernelGGL(ens_fwd2_kernel<3>, grid, dim3(ENT), E_LDS, st, a, b); break;
+  }
+  SERL_CHECK_LAUNCH("ensemble_fwd_fused_pair");
   return SERL_OK;
 }
