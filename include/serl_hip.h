@@ -259,7 +259,9 @@ int serl_policy_fwd_fused(const float* z, int ld_z, int din, int B, const float*
  * Dense, g1 / g0 = gradients w.r.t. the LayerNorm outputs (use_ln only; NULL otherwise) -- what serl_ln_act_bwd (rank-1
  * head form) + serl_gemm + serl_ln_act_bwd compute in three launches (sac_learner.py:200-211 differentiates
  * ensemble.py:8-22).  serl_ensemble_colsum: every batch-column sum of that backward in one launch -- head kernel / bias
- * gradient, LayerNorm scale / bias gradients (use_ln), Dense bias gradients; (E, 256) each, d_hb (E).  "bf16_3x" only. */
+ * gradient, LayerNorm scale / bias gradients (use_ln), Dense bias gradients; (E, 256) each, d_hb (E); with inp (B, ld_inp)
+ * and d_w0 (E, din, 256) non-NULL (din <= 32: the state-based learners) also the first Dense's kernel gradient
+ * d_w0[e] = inp^T dz0[e], in exact fp32.  serl_ensemble_bwd_fused: "bf16_3x" only. */
 int serl_ensemble_bwd_fused(const float* dq, int B, int E, const float* hw, const float* w1, const float* g0s,
                             const float* g1s, int use_ln, const float* h0, const float* h1, const float* xh0,
                             const float* xh1, const float* rs0, const float* rs1, float* dz1, float* g1, float* dz0,
@@ -267,7 +269,7 @@ int serl_ensemble_bwd_fused(const float* dq, int B, int E, const float* hw, cons
 int serl_ensemble_colsum(const float* dq, const float* h1, const float* g1, const float* xh1, const float* dz1,
                          const float* g0, const float* xh0, const float* dz0, int B, int E, int use_ln, float* d_hw,
                          float* d_hb, float* d_lnb1, float* d_lns1, float* d_b1, float* d_lnb0, float* d_lns0, float* d_b0,
-                         void* stream);
+                         const float* inp, int ld_inp, int din, float* d_w0, void* stream);
 /* behaviour-cloning losses: -mean log_prob of GIVEN actions (clipped to +-(1 - 1e-5), x = atanh(a)) under the tanh-Gaussian
  * policy with its gradient wrt mean / raw log-std (serl/agents/bc/pixel_bc_learner.py:114-134), info[0] = sum of the
  * per-row nll; sigmoid BCE of logits against (action column > 0) (pixel_hybrid_bc_learner.py:167-176), info[0] = sum. */

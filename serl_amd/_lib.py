@@ -51,7 +51,7 @@ _SIGS = {
     "serl_ensemble_fwd_fused_pair": [c_p, c_p, c_p],
     "serl_policy_fwd_fused": [c_p, c_i, c_i, c_i] + [c_p] * 8 + [c_i, c_u, c_u, c_i, c_i, c_i, c_p, c_i] + [c_p] * 6,
     "serl_ensemble_bwd_fused": [c_p, c_i, c_i] + [c_p] * 4 + [c_i] + [c_p] * 11,
-    "serl_ensemble_colsum": [c_p] * 8 + [c_i] * 3 + [c_p] * 9,
+    "serl_ensemble_colsum": [c_p] * 8 + [c_i] * 3 + [c_p] * 8 + [c_p, c_i, c_i, c_p, c_p],
     "serl_td_loss": [c_p, c_i, c_p, c_p, c_p, c_p, c_f, c_p, c_i, c_i, c_f, c_p, c_p, c_p, c_p],
     "serl_actor_loss": [c_p, c_i, c_i, c_p, c_p, c_p, c_p],
     "serl_adam_polyak": [c_p, c_p, c_p, c_p, c_p, c_ll, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p],

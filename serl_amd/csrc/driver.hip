@@ -744,10 +744,12 @@ int ensemble_bwd(serl_learner* h, char tag, const Store& s, const CriticOff& co,
                                 ln ? s.at(co.lns[1]) : nullptr, ln, h0, h1, xh0, xh1, rs0, rs1, dz1, g1, dz0, g0, st));
     if (grads) {
       if (gside) DRV(gside->fork(&stw));
+      const bool w0_here = dims[0] <= 32;   // state-based learners: the first kernel's gradient rides in the column-sum launch
       DRV(serl_ensemble_colsum(dq, h1, g1, xh1, dz1, g0, xh0, dz0, B, E, ln, grads->at(co.hk), grads->at(co.hb),
                                ln ? grads->at(co.lnb[1]) : nullptr, ln ? grads->at(co.lns[1]) : nullptr, grads->at(co.b[1]),
-                               ln ? grads->at(co.lnb[0]) : nullptr, ln ? grads->at(co.lns[0]) : nullptr, grads->at(co.b[0]), stw));
-      for (int i = 1; i >= 0; --i) {      // dW_i[e] = (input of layer i)^T . dz_i[e]
+                               ln ? grads->at(co.lnb[0]) : nullptr, ln ? grads->at(co.lns[0]) : nullptr, grads->at(co.b[0]),
+                               w0_here ? inp : nullptr, ld_inp, dims[0], w0_here ? grads->at(co.w[0]) : nullptr, stw));
+      for (int i = 1; i >= (w0_here ? 1 : 0); --i) {      // dW_i[e] = (input of layer i)^T . dz_i[e]
         const int hp = dims[i];
         const float* a_ptr = i == 0 ? inp : h0;
         G gg; gg.a = a_ptr; gg.b = i == 0 ? dz0 : dz1; gg.c = grads->at(co.w[i]); gg.nb = E; gg.M = hp; gg.N = 256; gg.K = B;

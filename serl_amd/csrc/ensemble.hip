@@ -608,19 +608,70 @@ __global__ __launch_bounds__(ENT, 1) void ens_bwd_kernel(const EnsBwdArgs a) {
 
 // Batch-column sums of the ensemble's backward in ONE launch (were two launches for the head and one per layer):
 //   job 0: d hw[e][n] = sum_b dq[e,b] h1[e,b,n],  d hb[e] = sum_b dq[e,b]
+//   job 3 (optional): the first Dense's kernel gradient, see EnsColsumArgs
 //   job 1 + l: d LNbias_l = sum_b g_l,  d LNscale_l = sum_b g_l xh_l,  d bias_l = sum_b dz_l      (no LayerNorm: d bias_l only)
 // Block (e, job, 64-column quarter): 1024 threads = 16 row groups x 64 columns; the partial sums are added in a fixed order.
 struct EnsColsumArgs {
   const float *dq, *h1, *g1, *xh1, *dz1, *g0, *xh0, *dz0;
   float *d_hw, *d_hb, *d_lnb1, *d_lns1, *d_b1, *d_lnb0, *d_lns0, *d_b0;   // member e at e * 256 (d_hb: e)
   int B, use_ln;
+  // optional (inp != nullptr, din <= CS_DIN): the first Dense's kernel gradient d_w0[e][m][n] = sum_b inp[b][m] dz0[e,b,n]
+  // as din weighted column sums in exact fp32 -- for the state-based learners (din = obs + action = 23) this replaces a
+  // GEMM launch of 13 us on the latency-bound chain by ~1 us of FMAs in the layer-0 job
+  const float* inp; int ld_inp, din; float* d_w0;
 };
 constexpr int CS_RG = 16, CS_COLS = 64;     // row groups x columns of a block: 1024 threads
+constexpr int CS_DIN = 32;
 __global__ __launch_bounds__(CS_RG * CS_COLS) void ens_colsum_kernel(const EnsColsumArgs a) {
   __shared__ float part[3][CS_RG][CS_COLS];
   const int e = blockIdx.x, job = blockIdx.y, cl = threadIdx.x & (CS_COLS - 1), rg = threadIdx.x / CS_COLS;
   const int n = blockIdx.z * CS_COLS + cl;
   const long long ro = (long long)e * a.B;
+  if (job == 3) {                              // d_w0[e][m][n] = sum_b inp[b][m] dz0[e,b,n]  (block-uniform branch)
+    extern __shared__ float cs_dyn[];
+    float* const xs = cs_dyn;                  // [256 rows][CS_DIN]: the input rows of the current chunk
+    float* const red = cs_dyn + 256 * CS_DIN;  // [16 row groups][16 m][64 columns]
+    float accw[CS_DIN];
+#pragma unroll
+    for (int m = 0; m < CS_DIN; ++m) accw[m] = 0.f;
+    for (int b0 = 0; b0 < a.B; b0 += 256) {
+      float z[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {           // this thread's 16 rows of the chunk: loads issued together
+        const int b = b0 + rg + CS_RG * u;
+        z[u] = a.dz0[(ro + min(b, a.B - 1)) * EH + n];
+      }
+      __syncthreads();                         // (the previous chunk's xs is no longer read)
+      for (int i = threadIdx.x; i < 256 * CS_DIN; i += CS_RG * CS_COLS) {
+        const int rr = i / CS_DIN, m = i - rr * CS_DIN, b = b0 + rr;
+        xs[i] = (b < a.B && m < a.din) ? a.inp[(long long)b * a.ld_inp + m] : 0.f;   // rows past B weigh 0
+      }
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const float* x = xs + (rg + CS_RG * u) * CS_DIN;      // wave-uniform row: broadcast reads
+#pragma unroll
+        for (int m4 = 0; m4 < CS_DIN; m4 += 4) {
+          const float4 xv = *reinterpret_cast<const float4*>(x + m4);
+          accw[m4] = fmaf(xv.x, z[u], accw[m4]); accw[m4 + 1] = fmaf(xv.y, z[u], accw[m4 + 1]);
+          accw[m4 + 2] = fmaf(xv.z, z[u], accw[m4 + 2]); accw[m4 + 3] = fmaf(xv.w, z[u], accw[m4 + 3]);
+        }
+      }
+    }
+#pragma unroll
+    for (int pass = 0; pass < CS_DIN / 16; ++pass) {
+      __syncthreads();
+#pragma unroll
+      for (int m = 0; m < 16; ++m) red[(rg * 16 + m) * CS_COLS + cl] = accw[pass * 16 + m];
+      __syncthreads();
+      const int m = pass * 16 + rg;            // this thread finishes (m, column): fixed order over the row groups
+      float t = red[(0 * 16 + rg) * CS_COLS + cl];
+#pragma unroll
+      for (int i = 1; i < CS_RG; ++i) t += red[(i * 16 + rg) * CS_COLS + cl];
+      if (m < a.din) a.d_w0[((long long)e * a.din + m) * EH + n] = t;
+    }
+    return;
+  }
   float s0 = 0.f, s1 = 0.f, s2 = 0.f;
   // rows rg, rg + 16, ...: eight rows per trip with their loads issued together (a rolled loop is one memory round trip
   // per row); rows past B read row B - 1 with weight 0
@@ -788,12 +839,24 @@ extern "C" int serl_ensemble_bwd_fused(const float* dq, int B, int E, const floa
 extern "C" int serl_ensemble_colsum(const float* dq, const float* h1, const float* g1, const float* xh1, const float* dz1,
                                     const float* g0, const float* xh0, const float* dz0, int B, int E, int use_ln,
                                     float* d_hw, float* d_hb, float* d_lnb1, float* d_lns1, float* d_b1, float* d_lnb0,
-                                    float* d_lns0, float* d_b0, void* stream) {
+                                    float* d_lns0, float* d_b0, const float* inp, int ld_inp, int din, float* d_w0,
+                                    void* stream) {
+  SERL_CHECK_ARG((inp == nullptr) == (d_w0 == nullptr), "ensemble_colsum: give inp and d_w0 together");
+  SERL_CHECK_ARG(!inp || (din >= 1 && din <= CS_DIN && ld_inp >= din), "ensemble_colsum: the fused first-kernel gradient takes din <= %d", CS_DIN);
   SERL_CHECK_ARG(dq && h1 && dz1 && dz0 && d_hw && d_hb && d_b1 && d_b0, "ensemble_colsum: null pointer");
   SERL_CHECK_ARG(!use_ln || (g1 && xh1 && g0 && xh0 && d_lnb1 && d_lns1 && d_lnb0 && d_lns0), "ensemble_colsum: LayerNorm operands missing");
   SERL_CHECK_ARG(B >= 1 && E >= 1, "ensemble_colsum: bad shape");
-  EnsColsumArgs a{dq, h1, g1, xh1, dz1, g0, xh0, dz0, d_hw, d_hb, d_lnb1, d_lns1, d_b1, d_lnb0, d_lns0, d_b0, B, use_ln};
-  hipLaunchKernelGGL(ens_colsum_kernel, dim3(E, 3, EH / CS_COLS), dim3(CS_RG * CS_COLS), 0, (hipStream_t)stream, a);
+  EnsColsumArgs a{dq, h1, g1, xh1, dz1, g0, xh0, dz0, d_hw, d_hb, d_lnb1, d_lns1, d_b1, d_lnb0, d_lns0, d_b0, B, use_ln,
+                  inp, ld_inp, din, d_w0};
+  constexpr int dyn = (256 * CS_DIN + CS_RG * 16 * CS_COLS) * 4;
+  static bool opted[64] = {};
+  int dev = 0;
+  SERL_CHECK_HIP(hipGetDevice(&dev), "ensemble_colsum");
+  if (dev >= 0 && dev < 64 && !opted[dev]) {
+    SERL_CHECK_HIP(hipFuncSetAttribute((const void*)ens_colsum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, dyn), "ensemble_colsum");
+    opted[dev] = true;
+  }
+  hipLaunchKernelGGL(ens_colsum_kernel, dim3(E, inp ? 4 : 3, EH / CS_COLS), dim3(CS_RG * CS_COLS), inp ? dyn : 0, (hipStream_t)stream, a);
   SERL_CHECK_LAUNCH("ensemble_colsum");
   return SERL_OK;
 }

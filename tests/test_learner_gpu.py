@@ -847,7 +847,8 @@ def test_fused_ensemble_backward_matches_unfused(dev, kind, monkeypatch):
         out[fused] = ({n: agent._shared[n].numpy_tree() for n in ("critic_grads", "actor_grads")}, info)
     # (pixel: the conv stack's backward amplifies the re-ordered sums; the actor step runs behind the critic's Adam step,
     # whose sign-like first update turns them into +-lr differences of single weights)
-    assert_tree_close(out["1"][0]["critic_grads"], out["0"][0]["critic_grads"], rtol=2e-5 if kind == "pixel" else 2e-6, what="critic_grads")
+    # (state: the fused path sums the first kernel's gradient in exact fp32 instead of bf16_3x products: 2^-16 per product)
+    assert_tree_close(out["1"][0]["critic_grads"], out["0"][0]["critic_grads"], rtol=2e-5, what="critic_grads")
     assert_tree_close(out["1"][0]["actor_grads"], out["0"][0]["actor_grads"], rtol=2e-4, what="actor_grads")
     for k in out["0"][1]:
         a, b = out["1"][1][k], out["0"][1][k]

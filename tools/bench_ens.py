@@ -35,7 +35,7 @@ def bwd():
 
 def colsum():
     _lib.call("serl_ensemble_colsum", p(dq), p(h1), p(g1), p(xh1), p(dz1), p(g0), p(xh0), p(dz0), B, E, 1, p(outs[0]),
-              p(outs[7]), p(outs[1]), p(outs[2]), p(outs[3]), p(outs[4]), p(outs[5]), p(outs[6]), st)
+              p(outs[7]), p(outs[1]), p(outs[2]), p(outs[3]), p(outs[4]), p(outs[5]), p(outs[6]), None, 0, 0, None, st)
 
 
 for name, fn in (("fwd", fwd), ("bwd", bwd), ("colsum", colsum)):
