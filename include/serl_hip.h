@@ -377,6 +377,13 @@ typedef struct {
  * MobileNet encoder, the backbone features of all rows are enqueued; the hook may enqueue work on the update's stream
  * that overwrites the batch's rewards before the first critic step reads them (VICELearner.update, vice_learner.py:300-308) */
 typedef int (*serl_allreduce_fn)(void* ctx, int which);
+/* Pixel learners with world > 1 split buffer 0 in two buckets (SERL_AMD_DP_OVERLAP=0: one all-reduce as above):
+ * which = 4: the SUFFIX of critic_grads behind the image_encoder leaves (trunk Dense / LayerNorms / ensemble: 17 of 21 MB
+ * at the headline config), called as soon as the kernels that write it are enqueued -- the hook must enqueue this
+ * all-reduce on the stream serl_learner_comm_stream returns, where it runs next to the encoder backward; which = 5: the
+ * image_encoder PREFIX, on the update's stream behind the last weight gradient.  The driver orders both against the
+ * optimizer step with events; no host synchronisation anywhere (the contract of an RCCL all-reduce).  No counterpart in
+ * the reference (single device; its commented-out batch split: serl/data/replay_buffer.py:85-98). */
 /* critic_offsets / actor_offsets: offsets in floats of every leaf of the flat stores in the layout order of
  * serl_amd/networks/spec.py (encoder + trunk leaves first for pixel learners), followed by the store's total size */
 int serl_learner_create(const serl_learner_config* cfg, const long long* critic_offsets, int n_critic,
@@ -415,6 +422,7 @@ int serl_learner_read_buffer(serl_learner* h, int B, const char* name, void* dst
 /* device address and size of a named workspace buffer ("bb_<side>_<cam>": the frozen backbone's features of the augmented
  * images, (n, fh, fw, fc) fp32) -- what a `features ready` hook (serl_allreduce_fn, which = 3) reads */
 int serl_learner_buffer_ptr(serl_learner* h, int B, const char* name, void** ptr, long long* nbytes);
+int serl_learner_comm_stream(serl_learner* h, void** stream);
 long long serl_learner_workspace_bytes(serl_learner* h);
 /* bench.py instrumentation: HIP events around every conv launch (on its launch stream) / between the phases of a step */
 int serl_learner_set_timing(serl_learner* h, int conv_events, int phase_events);

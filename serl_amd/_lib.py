@@ -91,6 +91,7 @@ _SIGS = {
     "serl_learner_bc_logit": [c_p, c_p, c_p, c_p, c_p, c_p],
     "serl_learner_read_buffer": [c_p, c_i, C.c_char_p, c_p, c_ll, c_p],
     "serl_learner_buffer_ptr": [c_p, c_i, C.c_char_p, c_p, c_p],
+    "serl_learner_comm_stream": [c_p, c_p],
     "serl_learner_workspace_bytes": [c_p],
     "serl_learner_set_timing": [c_p, c_i, c_i],
     "serl_learner_timing_count": [c_p],

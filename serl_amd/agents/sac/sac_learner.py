@@ -193,9 +193,11 @@ class SACLearner(Agent):
         ab.target, ab.temp = target.store.base, temp.buf.data_ptr()
         ab.critic_grads, ab.actor_grads = cgr.base, agr.base
         ab.actor_step, ab.critic_step, ab.temp_step = actor.step, critic.step, temp.step
+        nenc = self.critic.store.layout.prefix_size("image_encoder") if cfg.pixel else 0    # data-parallel buckets (native.py)
         with torch.cuda.device(dev):
             new_rng = self._native.update(ab, ub, utd_ratio, rng, info.data_ptr(), ops.current_stream(), dist=dist,
-                                          reduce_tensors=(cgr.flat, agr.flat, info[:4]), features_hook=features_hook)
+                                          reduce_tensors=(cgr.flat, agr.flat, info[:4], None, cgr.flat[nenc:], cgr.flat[:nenc]),
+                                          features_hook=features_hook)
         critic.step += utd_ratio
         actor.step += 1
         if self._HAS_TEMP:

@@ -16,6 +16,7 @@
 #include <math.h>
 
 #include <algorithm>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <unordered_map>
@@ -156,6 +157,11 @@ struct serl_learner {
   Workspace ws_act;
   std::mutex act_mu;
   hipStream_t s1 = nullptr, astream = nullptr;
+  // data parallel: the all-reduce of the critic gradient's trunk + ensemble leaves (17 of the 21 MB) is enqueued on this
+  // stream as soon as their gradient kernels are, i.e. next to the whole encoder backward; created on first use
+  hipStream_t comm = nullptr;
+  hipEvent_t comm_fork = nullptr, comm_done = nullptr;
+  bool dp_overlap = getenv("SERL_AMD_DP_OVERLAP") == nullptr || strcmp(getenv("SERL_AMD_DP_OVERLAP"), "0") != 0;
   GradSide gside, gside2;   // gside2: every other conv weight gradient (SERL_AMD_WG_STREAMS=2), so that it starts when its dz is ready
   // CU cap of the run-ahead pass's persistent patch kernels (default 7/8 of the CUs, set at creation; 0: none).  Their
   // blocks otherwise hold every CU for ~100 us at a time and the short kernels of the critic step's latency-bound chain
@@ -1032,12 +1038,15 @@ int features(serl_learner* h, const FPass* passes, int npass, const Feats& f, in
 
 int features_bwd(serl_learner* h, char tag, const Store& store, const EncOff& eo, const Store& grads, const Feats& f, int lo,
                  int B, Workspace& ws, hipStream_t st, const float* dz, int lddz, bool need_encoder, GradSide* gside,
-                 int dz_nslab, long long dz_ss, const uint32_t* drop = nullptr) {
+                 int dz_nslab, long long dz_ss, const uint32_t* drop = nullptr,
+                 const std::function<int()>* after_trunk = nullptr) {
   const Cfg& c = h->cfg;
   if (!c.pixel) return SERL_OK;   // no trainable feature stage for state inputs
   WSF(ws, st, z, (size_t)B * c.ldz, "z%c", tag);
   DRV(trunk_bwd(h, tag, store, eo, grads, f.state + (size_t)lo * c.state_dim, z, c.ldz, dz, lddz, B, ws, st, need_encoder,
                 gside, dz_nslab, dz_ss));
+  // every gradient kernel of the ensemble and trunk leaves is enqueued: the data-parallel bucket of those leaves starts here
+  if (after_trunk) DRV((*after_trunk)());
   if (need_encoder && c.encoder == 1) {
     // frozen backbone: the gradient stops at its feature map; only the spatial-embedding kernels are trained.  Backward
     // of the Dropout = the same mask on the gradient, then dK[h,w,c,f] = sum_b feat[b,h,w,c] denc[b,c,f].
@@ -1306,6 +1315,9 @@ extern "C" int serl_learner_destroy(serl_learner* h) {
   if (h->astream) (void)hipStreamDestroy(h->astream);
   if (h->gside.own) (void)hipStreamDestroy(h->gside.own);
   for (hipEvent_t e : h->gside.ev) (void)hipEventDestroy(e);
+  if (h->comm) (void)hipStreamDestroy(h->comm);
+  for (hipEvent_t e : {h->comm_fork, h->comm_done})
+    if (e) (void)hipEventDestroy(e);
   if (h->gside2.own) (void)hipStreamDestroy(h->gside2.own);
   for (hipEvent_t e : h->gside2.ev) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->adone) (void)hipEventDestroy(e);
@@ -1492,11 +1504,32 @@ extern "C" int serl_learner_update(serl_learner* h, const serl_agent_buffers* ag
     DRV(ensemble_bwd(h, 'C', critic, co, &cgr, dq, zC, ldz, B, ws, st, &h->gside, c.pixel ? 2 : 0, &dinp, &nslab, &ss,
                      &step_keys[8 * i + 6], rank * B, Bg));
     DRV(phase(h, "ensemble_bwd", st));
-    DRV(features_bwd(h, 'C', critic, co.e, cgr, f, lo, B, ws, st, dinp, ldz, true, &h->gside, nslab, ss, &step_keys[8 * i + 6]));
+    // data parallel, pixel learners: two buckets.  Bucket 4 = the trunk + ensemble leaves (the suffix of the flat gradient:
+    // Dense(4096 -> 512), LayerNorms, 10 critics = 17 of 21 MB), all-reduced on the comm stream behind their gradient
+    // kernels and NEXT TO the encoder backward; bucket 5 = the encoder leaves, on the main stream once the last weight
+    // gradient is in.  The hook enqueues bucket 4 on the stream serl_learner_comm_stream returns.
+    const bool dp_overlap = world > 1 && multi && h->dp_overlap;
+    const std::function<int()> bucket4 = [&]() -> int {
+      DRV(link(h->gside.side, h->comm, h->comm_fork));
+      DRV(allreduce(allreduce_ctx, 4));
+      DRV_HIP(hipEventRecord(h->comm_done, h->comm));
+      return SERL_OK;
+    };
+    if (dp_overlap && !h->comm) {
+      void* unused = nullptr;
+      DRV(serl_learner_comm_stream(h, &unused));
+    }
+    DRV(features_bwd(h, 'C', critic, co.e, cgr, f, lo, B, ws, st, dinp, ldz, true, &h->gside, nslab, ss, &step_keys[8 * i + 6],
+                     dp_overlap ? &bucket4 : nullptr));
     DRV(h->gside.join());
     DRV(h->gside2.join());
     DRV(phase(h, "features_bwd", st));
-    if (world > 1) DRV(allreduce(allreduce_ctx, 0));   // data parallel: one all-reduce(sum) of the flat gradient per step
+    if (dp_overlap) {
+      DRV(allreduce(allreduce_ctx, 5));
+      DRV_HIP(hipStreamWaitEvent(st, h->comm_done, 0));
+    } else if (world > 1) {
+      DRV(allreduce(allreduce_ctx, 0));   // one all-reduce(sum) of the flat gradient per step
+    }
     ++critic_step;
     float bc1, bc2;
     bias_corrections(critic_step, &bc1, &bc2);
@@ -1721,6 +1754,18 @@ extern "C" int serl_learner_buffer_ptr(serl_learner* h, int B, const char* name,
   SERL_CHECK_ARG(it != w->second.m.end(), "learner_buffer_ptr: no buffer named %s", name);
   *ptr = it->second.p;
   if (nbytes) *nbytes = (long long)it->second.bytes;
+  return SERL_OK;
+}
+
+// The stream the data-parallel hook must enqueue bucket 4 on (which = 4); created on first use.
+extern "C" int serl_learner_comm_stream(serl_learner* h, void** stream) {
+  SERL_CHECK_ARG(h && stream, "learner_comm_stream: null pointer");
+  if (!h->comm) {
+    DRV_HIP(hipStreamCreateWithFlags(&h->comm, hipStreamNonBlocking));
+    DRV_HIP(hipEventCreateWithFlags(&h->comm_fork, hipEventDisableTiming));
+    DRV_HIP(hipEventCreateWithFlags(&h->comm_done, hipEventDisableTiming));
+  }
+  *stream = (void*)h->comm;
   return SERL_OK;
 }
 

@@ -112,6 +112,14 @@ class NativeLearner:
             except Exception:       # noqa: BLE001  interpreter shutdown
                 pass
 
+    def _comm_stream(self):
+        """torch view of the handle's communication stream (serl_learner_comm_stream)."""
+        if getattr(self, "_comm", None) is None:
+            p = C.c_void_p()
+            _lib.call("serl_learner_comm_stream", self._h, C.byref(p))
+            self._comm = torch.cuda.ExternalStream(p.value)
+        return self._comm
+
     def set_backbone(self, backbone):
         """The frozen MobileNetV3 feature extractor (serl_amd.networks.mobilenet.Backbone) of a mobilenet-encoder learner."""
         self._backbone = backbone          # keeps the device buffer alive
@@ -120,7 +128,8 @@ class NativeLearner:
     # ------------------------------------------------------------------ update
     def update(self, buffers: AgentBuffers, batch: UpdateBatch, utd_ratio, rng, info_out, stream, dist=None,
                reduce_tensors=None, features_hook=None):
-        """-> new rng (uint32[2]).  reduce_tensors: (critic_grads, actor_grads, info[:4]) torch tensors for `dist`.
+        """-> new rng (uint32[2]).  reduce_tensors: (critic_grads, actor_grads, info[:4], None, critic_grads suffix behind the
+        image_encoder leaves, image_encoder prefix) torch tensors for `dist` (serl_allreduce_fn's `which`).
         features_hook(): called once the augmented images / backbone features of all rows are enqueued (VICE rewards)."""
         rin = (C.c_uint * 2)(int(rng[0]), int(rng[1]))
         rout = (C.c_uint * 2)()
@@ -135,6 +144,9 @@ class NativeLearner:
                 try:
                     if which == 3:
                         features_hook()
+                    elif which == 4:        # trunk + ensemble bucket: on the driver's comm stream, next to the encoder backward
+                        with torch.cuda.stream(self._comm_stream()):
+                            dist.all_reduce_sum(reduce_tensors[4])
                     else:
                         if _DP_TRACE:
                             print(f"[dp rank {rank}] all-reduce {which} ({reduce_tensors[which].numel()} elements) ...", file=sys.stderr, flush=True)

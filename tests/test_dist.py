@@ -147,3 +147,107 @@ def test_dp_learner_two_ranks_equals_one(dev, large):
     assert np.abs(g1 - grads2).max() <= 2e-2 * np.abs(g1).max()       # last UTD step, after one Adam step of drift
     assert np.abs(new.critic.store.flat.cpu().numpy() - critic2).max() <= 2.5 * 3e-4 * 2
     assert np.abs(new.actor.store.flat.cpu().numpy() - actor2).max() <= 2.5 * 3e-4
+
+
+class _PairDP:
+    """Two emulated ranks in ONE process (two threads, two streams, one GPU) with the ordering contract of an RCCL
+    all-reduce: the sum is ENQUEUED on the caller's current stream, ordered against the peer's producer / consumer
+    kernels by events only -- no host-side wait for the GPU anywhere (the host barrier below only makes sure the peer
+    has enqueued its work, as a collective's rendezvous does).  The gloo path of serl_amd.dist blocks on a host copy and
+    therefore cannot show a missing stream dependency between all-reduce, gradient side streams and the optimizer step;
+    this one does.  Sum order fixed (rank 0 + rank 1): both ranks hold the same bits."""
+
+    class Shared:
+        def __init__(self):
+            import threading
+            self.barrier = threading.Barrier(2, timeout=120)
+            self.slot = [None, None]
+            self.read = [None, None]
+            self.calls = [0, 0]
+
+    def __init__(self, rank, shared):
+        self.rank, self.world_size, self.sh = rank, 2, shared
+
+    def all_reduce_sum(self, t):
+        sh, r, o = self.sh, self.rank, 1 - self.rank
+        st = torch.cuda.current_stream()
+        ready = torch.cuda.Event()
+        ready.record(st)
+        sh.slot[r] = (t, ready)
+        sh.calls[r] += 1
+        sh.barrier.wait()
+        ot, oready = sh.slot[o]
+        assert ot.numel() == t.numel(), "the ranks disagree on the bucket"
+        st.wait_event(oready)                               # the peer's gradient kernels
+        tmp = (t + ot) if r == 0 else (ot + t)
+        done = torch.cuda.Event()
+        done.record(st)
+        sh.read[r] = done
+        sh.barrier.wait()
+        st.wait_event(sh.read[o])                           # the peer has read my buffer before I overwrite it
+        t.copy_(tmp)
+        sh.barrier.wait()
+        return t
+
+
+def _pair_case(large):
+    c = _gpu_case(large)
+    if large:
+        c = dict(c, bg=128)
+    return c
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("overlap", ["1", "0"])
+@pytest.mark.parametrize("large", [False, True])
+def test_dp_stream_ordered_pair_equals_one_rank(dev, large, overlap, monkeypatch):
+    """world = 2 on one GPU with a stream-ordered, host-sync-free all-reduce (_PairDP): the two ranks' results equal the
+    single-rank run on the global batch -- with the gradient in two buckets, the trunk + ensemble bucket all-reduced on the
+    driver's comm stream next to the encoder backward (SERL_AMD_DP_OVERLAP=1, default), and with one all-reduce per step."""
+    import threading
+    from helpers import make_pixel_batch, pixel_spaces
+    from oracle import learner as ol
+    from serl_amd.agents import DrQLearner
+    from serl_amd.dist import shard_rows
+    monkeypatch.setenv("SERL_AMD_DP_OVERLAP", overlap)          # read when the native handle is created
+    c = _pair_case(large)
+    keys, H, W, S, bg, utd = c["keys"], c["H"], c["W"], c["S"], c["bg"], c["utd"]
+    obs_space, act_space = pixel_spaces(keys, H, W, S, 19, 7)
+    batch = make_pixel_batch(np.random.default_rng(2), bg * utd, keys, H, W, S, 19, 7, packed=True)
+    shared = _PairDP.Shared()
+    res, errs = [None, None], []
+
+    def rank_main(rank):
+        try:
+            torch.cuda.set_device(0)
+            with torch.cuda.stream(torch.cuda.Stream()):
+                agent = DrQLearner.create(5, obs_space, act_space, pixel_keys=keys, dist=_PairDP(rank, shared), **c["kw"])
+                local = ol.tree_map(lambda a: a[shard_rows(bg * utd, utd, rank, 2)], batch)
+                new, info = agent.update(local, utd, pixel_keys=keys)
+                info = dict(info)
+                torch.cuda.current_stream().synchronize()
+                res[rank] = (info, new.critic.store.flat.clone(), new.actor.store.flat.clone(),
+                             agent._shared["critic_grads"].flat.clone())
+        except Exception as e:      # noqa: BLE001
+            errs.append((rank, repr(e)))
+            shared.barrier.abort()
+    ts = [threading.Thread(target=rank_main, args=(r,)) for r in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=200)
+    assert not errs, errs
+    torch.cuda.synchronize()
+    # the ranks agree bit for bit (same summed gradients, same optimizer arithmetic)
+    assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2]) and res[0][0] == res[1][0]
+    # per critic step: 2 buckets (overlap) or 1 all-reduce, + actor gradient + info at the end
+    assert shared.calls[0] == shared.calls[1] == (2 * utd if overlap == "1" else utd) + 2
+    agent = DrQLearner.create(5, obs_space, act_space, pixel_keys=keys, **c["kw"])
+    new, info1 = agent.update(batch, utd, pixel_keys=keys)
+    info2 = res[0][0]
+    for k in info1:
+        assert abs(info1[k] - info2[k]) <= 2e-4 * max(abs(info1[k]), 1e-2), (k, dict(info1), info2)
+    g1 = agent._shared["critic_grads"].flat
+    assert float((g1 - res[0][3]).abs().max()) <= 2e-2 * float(g1.abs().max())      # last UTD step, after one Adam step of drift
+    assert float((new.critic.store.flat - res[0][1]).abs().max()) <= 2.5 * 3e-4 * 2
+    assert float((new.actor.store.flat - res[0][2]).abs().max()) <= 2.5 * 3e-4
