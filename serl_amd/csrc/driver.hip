@@ -33,7 +33,87 @@
   } while (0)
 #define DRV_HIP(expr) SERL_CHECK_HIP(expr, "learner")
 
+#include <chrono>
 namespace {
+
+// SERL_AMD_HOST_PROF=1: host time of the driver by category (event record / wait calls, workspace lookups, whole update
+// calls), printed when a handle is destroyed -- where the ~10 ms of CPU time per pixel update go
+struct HostProf {
+  bool on = getenv("SERL_AMD_HOST_PROF") != nullptr && atoi(getenv("SERL_AMD_HOST_PROF")) != 0;
+  double t_rec = 0, t_wait = 0, t_ws = 0, t_upd = 0;
+  long n_rec = 0, n_wait = 0, n_ws = 0, n_upd = 0;
+  static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+};
+HostProf g_hp;
+// Cross-stream dependencies.  hipStreamWaitEvent costs ~15-22 us of HOST time per call on this ROCm (tools/wait_cost.py;
+// 222 of them per pixel update = 4.7-5.3 of its ~10 ms of CPU time), a stream memory operation ~3 us stand-alone.
+// OPTION (SERL_AMD_VALUE_WAITS=1, off by default): every event of the driver carries an 8-byte signal word
+// (hipMallocSignalMemory), "record" = hipStreamWriteValue32 of the next sequence number behind the work enqueued so far,
+// "wait" = hipStreamWaitValue32(>= the number of the latest record) -- the semantics of hipEventRecord /
+// hipStreamWaitEvent (a wait refers to the most recent record at the time of the call; the producer's write is always
+// enqueued before the consumer's wait, so no wait can be left without its write).  Measured inside the update (round 3,
+// two interleaved runs each): waits 4.7 -> 0.5 ms of host time per update, but the write calls cost 3.2 ms behind queued
+// kernels (0.3 ms as event records) and the GPU side is SLOWER -- 34.8 vs 32.6 ms per update (the command processor
+// polls the word instead of being signalled) -- so the events stay.  All GPU tests pass in either mode.
+struct EvSig { uint32_t* word = nullptr; uint32_t last = 0; bool tried = false; };
+std::unordered_map<hipEvent_t, EvSig> g_sigs;
+std::mutex g_sig_mu;
+const bool g_value_waits = getenv("SERL_AMD_VALUE_WAITS") != nullptr && atoi(getenv("SERL_AMD_VALUE_WAITS")) != 0;
+inline EvSig* ev_sig(hipEvent_t e) {      // call with g_sig_mu held
+  EvSig& g = g_sigs[e];
+  if (!g.tried) {
+    g.tried = true;
+    void* p = nullptr;
+    if (hipExtMallocWithFlags(&p, 8, hipMallocSignalMemory) == hipSuccess && p) {
+      if (hipMemset(p, 0, 8) == hipSuccess) g.word = (uint32_t*)p;
+      else (void)hipFree(p);
+    } else {
+      (void)hipGetLastError();
+    }
+  }
+  return g.word ? &g : nullptr;
+}
+inline hipError_t ev_record(hipEvent_t e, hipStream_t s) {
+  const double t0 = g_hp.on ? HostProf::now() : 0;
+  hipError_t r;
+  EvSig* g = nullptr;
+  uint32_t val = 0;
+  if (g_value_waits) {
+    std::lock_guard<std::mutex> lock(g_sig_mu);
+    g = ev_sig(e);
+    if (g) val = ++g->last;
+  }
+  r = g ? hipStreamWriteValue32(s, g->word, val, 0) : hipEventRecord(e, s);
+  if (g_hp.on) { g_hp.t_rec += HostProf::now() - t0; ++g_hp.n_rec; }
+  return r;
+}
+inline hipError_t ev_wait(hipStream_t s, hipEvent_t e) {
+  const double t0 = g_hp.on ? HostProf::now() : 0;
+  hipError_t r;
+  uint32_t* word = nullptr;
+  uint32_t val = 0;
+  if (g_value_waits) {
+    std::lock_guard<std::mutex> lock(g_sig_mu);
+    EvSig* g = ev_sig(e);
+    if (g) { word = g->word; val = g->last; }
+  }
+  if (word) r = val == 0 ? hipSuccess : hipStreamWaitValue32(s, word, val, hipStreamWaitValueGte, 0xFFFFFFFFu);   // (never recorded: nothing to wait for)
+  else r = hipStreamWaitEvent(s, e, 0);
+  if (g_hp.on) { g_hp.t_wait += HostProf::now() - t0; ++g_hp.n_wait; }
+  return r;
+}
+inline void ev_destroy(hipEvent_t e) {
+  if (!e) return;
+  {
+    std::lock_guard<std::mutex> lock(g_sig_mu);
+    auto it = g_sigs.find(e);
+    if (it != g_sigs.end()) {
+      if (it->second.word) (void)hipFree(it->second.word);
+      g_sigs.erase(it);
+    }
+  }
+  (void)hipEventDestroy(e);
+}
 
 constexpr int TRUNK_DIM = 512;    // hard-coded in serl/networks/pixel_multiplexer.py:34
 constexpr int SLE_FEATURES = 8;   // two_d4pg_encoder.py:40
@@ -70,12 +150,26 @@ struct Store {   // a flat fp32 parameter (or gradient) buffer
 
 // ---------------------------------------------------------------- named, lazily allocated device buffers
 struct Workspace {
-  struct Buf { void* p; size_t bytes; };
-  std::unordered_map<std::string, Buf> m;
+  struct Buf { void* p; size_t bytes; std::string name; };
+  // keyed by a 64-bit FNV-1a hash of the name (the name itself is kept and compared on a hit): the ~250 lookups of a
+  // critic step no longer build a std::string each
+  std::unordered_map<uint64_t, Buf> m;
   char name[96];
 
+  static uint64_t hash_name(const char* s) {
+    uint64_t h = 1469598103934665603ull;
+    for (; *s; ++s) { h ^= (unsigned char)*s; h *= 1099511628211ull; }
+    return h;
+  }
+  const Buf* find(const char* nm) const {
+    auto it = m.find(hash_name(nm));
+    return (it != m.end() && it->second.name == nm) ? &it->second : nullptr;
+  }
   int get(size_t bytes, void** out, hipStream_t st) {
-    auto it = m.find(name);
+    ++g_hp.n_ws;
+    const uint64_t key = hash_name(name);
+    auto it = m.find(key);
+    if (it != m.end()) SERL_CHECK_ARG(strcmp(it->second.name.c_str(), name) == 0, "workspace: name hash collision (%s / %s)", name, it->second.name.c_str());
     if (it != m.end() && it->second.bytes == bytes) { *out = it->second.p; return SERL_OK; }
     if (it != m.end()) {   // shape of a name changed: rare (another batch size reuses the handle's act workspace)
       DRV_HIP(hipDeviceSynchronize());
@@ -87,7 +181,7 @@ struct Workspace {
     // zero fill; the buffer may be used on any of the driver's streams: wait for the fill once, on first use of a name
     DRV_HIP(hipMemsetAsync(p, 0, bytes ? bytes : 4, st));
     DRV_HIP(hipStreamSynchronize(st));
-    m[name] = Buf{p, bytes};
+    m[key] = Buf{p, bytes, name};
     *out = p;
     return SERL_OK;
   }
@@ -131,8 +225,8 @@ struct GradSide {   // side stream for parameter-gradient kernels: fork() = side
     if (side == main) { *out = main; return SERL_OK; }
     hipEvent_t e;
     DRV(next(&e));
-    DRV_HIP(hipEventRecord(e, main));
-    DRV_HIP(hipStreamWaitEvent(side, e, 0));
+    DRV_HIP(ev_record(e, main));
+    DRV_HIP(ev_wait(side, e));
     *out = side;
     return SERL_OK;
   }
@@ -140,8 +234,8 @@ struct GradSide {   // side stream for parameter-gradient kernels: fork() = side
     if (side == main) return SERL_OK;
     hipEvent_t e;
     DRV(next(&e));
-    DRV_HIP(hipEventRecord(e, side));
-    DRV_HIP(hipStreamWaitEvent(main, e, 0));
+    DRV_HIP(ev_record(e, side));
+    DRV_HIP(ev_wait(main, e));
     return SERL_OK;
   }
 };
@@ -274,8 +368,8 @@ struct Timed {   // RAII-free bracket: begin() before the launch, end() after, b
 // `to` waits for everything enqueued on `from` so far (no-op when they are the same stream)
 int link(hipStream_t from, hipStream_t to, hipEvent_t ev) {
   if (from == to) return SERL_OK;
-  DRV_HIP(hipEventRecord(ev, from));
-  DRV_HIP(hipStreamWaitEvent(to, ev, 0));
+  DRV_HIP(ev_record(ev, from));
+  DRV_HIP(ev_wait(to, ev));
   return SERL_OK;
 }
 
@@ -1308,21 +1402,26 @@ extern "C" int serl_learner_set_backbone(serl_learner* h, const float* params) {
 
 extern "C" int serl_learner_destroy(serl_learner* h) {
   if (!h) return SERL_OK;
+  if (g_hp.on && g_hp.n_upd > 0) {
+    fprintf(stderr, "[host prof] %ld update calls: %.3f ms each; per call: %.1f event records %.3f ms, %.1f stream waits %.3f ms, "
+            "%.0f workspace lookups\n", g_hp.n_upd, g_hp.t_upd / g_hp.n_upd * 1e3, (double)g_hp.n_rec / g_hp.n_upd,
+            g_hp.t_rec / g_hp.n_upd * 1e3, (double)g_hp.n_wait / g_hp.n_upd, g_hp.t_wait / g_hp.n_upd * 1e3,
+            (double)g_hp.n_ws / g_hp.n_upd);
+    g_hp = HostProf{};
+  }
   (void)hipDeviceSynchronize();
   for (auto& kv : h->ws_update) kv.second.release();
   h->ws_act.release();
   if (h->s1) (void)hipStreamDestroy(h->s1);
   if (h->astream) (void)hipStreamDestroy(h->astream);
   if (h->gside.own) (void)hipStreamDestroy(h->gside.own);
-  for (hipEvent_t e : h->gside.ev) (void)hipEventDestroy(e);
+  for (hipEvent_t e : h->gside.ev) ev_destroy(e);
   if (h->comm) (void)hipStreamDestroy(h->comm);
-  for (hipEvent_t e : {h->comm_fork, h->comm_done})
-    if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : {h->comm_fork, h->comm_done}) ev_destroy(e);
   if (h->gside2.own) (void)hipStreamDestroy(h->gside2.own);
-  for (hipEvent_t e : h->gside2.ev) (void)hipEventDestroy(e);
-  for (hipEvent_t e : h->adone) (void)hipEventDestroy(e);
-  for (hipEvent_t e : {h->fork_ev, h->join1, h->astart, h->agate, h->aobs})
-    if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : h->gside2.ev) ev_destroy(e);
+  for (hipEvent_t e : h->adone) ev_destroy(e);
+  for (hipEvent_t e : {h->fork_ev, h->join1, h->astart, h->agate, h->aobs}) ev_destroy(e);
   for (auto& r : h->trecs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   for (auto& r : h->precs) (void)hipEventDestroy(r.ev);
   delete h;
@@ -1334,6 +1433,7 @@ extern "C" int serl_learner_update(serl_learner* h, const serl_agent_buffers* ag
                                    const unsigned* rng_in, unsigned* rng_out, float* info_out, void* stream,
                                    serl_allreduce_fn allreduce, void* allreduce_ctx, int rank, int world) {
   SERL_CHECK_ARG(h && ag && bt && rng_in && rng_out && info_out, "learner_update: null pointer");
+  struct UpdTimer { double t0 = g_hp.on ? HostProf::now() : 0; ~UpdTimer() { if (g_hp.on) { g_hp.t_upd += HostProf::now() - t0; ++g_hp.n_upd; } } } upd_timer;
   SERL_CHECK_ARG(utd >= 1 && bt->n >= utd && bt->n % utd == 0, "learner_update: batch of %d rows is not divisible by utd_ratio %d", bt->n, utd);
   SERL_CHECK_ARG(world >= 1 && rank >= 0 && rank < world && (world == 1 || allreduce), "learner_update: bad rank / world / allreduce");
   const Cfg& c = h->cfg;
@@ -1439,7 +1539,7 @@ extern "C" int serl_learner_update(serl_learner* h, const serl_agent_buffers* ag
     DRV(policy_fwd(h, 'A', actor, ao, zA, ldz, B, ws, sta, &step_keys[8 * j], rank * B, Bg,
                    zT_all + ((size_t)j * B * ldz + c.latent), ldz, false, false, c.backup_entropy != 0,
                    nlogp_all + (size_t)j * B, nullptr));
-    if (sta != st) DRV_HIP(hipEventRecord(h->adone[j], sta));
+    if (sta != st) DRV_HIP(ev_record(h->adone[j], sta));
     return SERL_OK;
   };
   auto enqueue_actor_obs = [&]() -> int {   // behind the last pass: the actor's own pass over obs for the actor step
@@ -1453,7 +1553,7 @@ extern "C" int serl_learner_update(serl_learner* h, const serl_agent_buffers* ag
     DRV(fe);
     DRV(policy_fwd(h, 'A', actor, ao, zA, ldz, B, ws, sta, key_pi, rank * B, Bg, zP + c.latent, ldz, false, true, true, logpA,
                    nullptr));
-    if (sta != st) DRV_HIP(hipEventRecord(h->aobs, sta));
+    if (sta != st) DRV_HIP(ev_record(h->aobs, sta));
     return SERL_OK;
   };
   DRV(enqueue_actor(0));
@@ -1478,7 +1578,7 @@ extern "C" int serl_learner_update(serl_learner* h, const serl_agent_buffers* ag
     DRV(link(st, sta, h->agate));
     if (i + 1 < utd) DRV(enqueue_actor(i + 1));
     else DRV(enqueue_actor_obs());
-    if (sta != st) DRV_HIP(hipStreamWaitEvent(st, h->adone[i], 0));
+    if (sta != st) DRV_HIP(ev_wait(st, h->adone[i]));
     float *next_q, *q;
     if (!multi && c.crit_drop <= 0.f && ens_fwd_fusable(h)) {
       // state-based learners: target and critic passes share the caller's stream -> one launch for both
@@ -1512,7 +1612,7 @@ extern "C" int serl_learner_update(serl_learner* h, const serl_agent_buffers* ag
     const std::function<int()> bucket4 = [&]() -> int {
       DRV(link(h->gside.side, h->comm, h->comm_fork));
       DRV(allreduce(allreduce_ctx, 4));
-      DRV_HIP(hipEventRecord(h->comm_done, h->comm));
+      DRV_HIP(ev_record(h->comm_done, h->comm));
       return SERL_OK;
     };
     if (dp_overlap && !h->comm) {
@@ -1526,7 +1626,7 @@ extern "C" int serl_learner_update(serl_learner* h, const serl_agent_buffers* ag
     DRV(phase(h, "features_bwd", st));
     if (dp_overlap) {
       DRV(allreduce(allreduce_ctx, 5));
-      DRV_HIP(hipStreamWaitEvent(st, h->comm_done, 0));
+      DRV_HIP(ev_wait(st, h->comm_done));
     } else if (world > 1) {
       DRV(allreduce(allreduce_ctx, 0));   // one all-reduce(sum) of the flat gradient per step
     }
@@ -1541,7 +1641,7 @@ extern "C" int serl_learner_update(serl_learner* h, const serl_agent_buffers* ag
   DRV(phase(h, "actor", st));
   const int lo = (utd - 1) * B;
   // the actor's own pass over obs ran ahead; only the critic pass with the post-UTD critic parameters is left here
-  if (sta != st) DRV_HIP(hipStreamWaitEvent(st, h->aobs, 0));
+  if (sta != st) DRV_HIP(ev_wait(st, h->aobs));
   {
     FPass p{'C', critic, &co.e, 0, zP, st, key_drop_pi};
     DRV(features(h, &p, 1, f, lo, B, ws, st, 0, nullptr, true));
@@ -1739,10 +1839,10 @@ extern "C" int serl_learner_read_buffer(serl_learner* h, int B, const char* name
   SERL_CHECK_ARG(h && name && dst && nbytes >= 0, "learner_read_buffer: bad args");
   auto w = h->ws_update.find(B);
   SERL_CHECK_ARG(w != h->ws_update.end(), "learner_read_buffer: no update with minibatch size %d has run", B);
-  auto it = w->second.m.find(name);
-  SERL_CHECK_ARG(it != w->second.m.end(), "learner_read_buffer: no buffer named %s", name);
-  SERL_CHECK_ARG((size_t)nbytes <= it->second.bytes, "learner_read_buffer: %s holds %zu bytes", name, it->second.bytes);
-  DRV_HIP(hipMemcpyAsync(dst, it->second.p, (size_t)nbytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  const Workspace::Buf* it = w->second.find(name);
+  SERL_CHECK_ARG(it != nullptr, "learner_read_buffer: no buffer named %s", name);
+  SERL_CHECK_ARG((size_t)nbytes <= it->bytes, "learner_read_buffer: %s holds %zu bytes", name, it->bytes);
+  DRV_HIP(hipMemcpyAsync(dst, it->p, (size_t)nbytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return SERL_OK;
 }
 
@@ -1750,10 +1850,10 @@ extern "C" int serl_learner_buffer_ptr(serl_learner* h, int B, const char* name,
   SERL_CHECK_ARG(h && name && ptr, "learner_buffer_ptr: bad args");
   auto w = h->ws_update.find(B);
   SERL_CHECK_ARG(w != h->ws_update.end(), "learner_buffer_ptr: no update with minibatch size %d has run", B);
-  auto it = w->second.m.find(name);
-  SERL_CHECK_ARG(it != w->second.m.end(), "learner_buffer_ptr: no buffer named %s", name);
-  *ptr = it->second.p;
-  if (nbytes) *nbytes = (long long)it->second.bytes;
+  const Workspace::Buf* it = w->second.find(name);
+  SERL_CHECK_ARG(it != nullptr, "learner_buffer_ptr: no buffer named %s", name);
+  *ptr = it->p;
+  if (nbytes) *nbytes = (long long)it->bytes;
   return SERL_OK;
 }
 

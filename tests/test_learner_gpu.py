@@ -749,7 +749,7 @@ def test_full_size_patch_vs_im2col_update(dev):
             assert np.array_equal(a, b), f"gradient leaf {'/'.join(path)} differs between patch and im2col kernels"
     assert nsummed == 4
     # the actor step runs on the critic AFTER its Adam step (sac_learner.py:235), i.e. behind conv2's re-ordered sums
-    assert_tree_close(res[1][0]["actor_grads"], res[0][0]["actor_grads"], rtol=1e-4, what="actor grads")
+    assert_tree_close(res[1][0]["actor_grads"], res[0][0]["actor_grads"], rtol=5e-4, what="actor grads")
     for k in res[0][1]:
         for which in (1, 2):
             a, b = float(res[1][which][k]), float(res[0][which][k])
