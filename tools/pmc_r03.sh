@@ -17,8 +17,10 @@ for P in "$P1" "$P2" "$P3"; do
     CMD="$CMD && timeout -s KILL 120 rocprofv3 --pmc $P --output-format csv -d \$GRAFT_REPO_ROOT/$D/${S}_p$i -- python3 \$GRAFT_REPO_ROOT/tools/$S.py > \$GRAFT_REPO_ROOT/$D/${S}_p$i.out 2>&1"
   done
 done
+if [ -z "$PMC_PARSE_ONLY" ]; then
 rm -rf $D
 /usr/local/graft/bin/gpurun --timeout 900 -- "$CMD; echo done" 2>&1 | tail -3
+fi
 python3 - "$OUT" <<'PY'
 import csv, glob, collections, sys
 NAMES = [("pconv_fused12pp_kernel", "layers 1+2 fused, no-gradient passes (pconv_fused12pp_kernel), 2 groups"),
@@ -55,7 +57,7 @@ with open(sys.argv[1], "w") as out:
             w(f"   {k:32s} {v[k]:16.0f}")
         try:
             wc, bc = v["SQ_WAVE_CYCLES"], v["SQ_BUSY_CU_CYCLES"]
-            w(f"   -> MFMA busy / CU busy cycles {v['SQ_VALU_MFMA_BUSY_CYCLES'] / bc:.3f};  occupancy (wave cycles / CU busy cycles) {wc / bc:.2f} waves;  "
+            w(f"   -> MFMA pipe busy share (MFMA busy cycles / (4 SIMDs x CU busy cycles)) {v['SQ_VALU_MFMA_BUSY_CYCLES'] / (4 * bc):.3f};  occupancy (wave cycles / CU busy cycles) {wc / bc:.2f} waves;  "
               f"VALU active / busy {v['SQ_ACTIVE_INST_VALU'] / bc:.2f};  LDS active / busy {v['SQ_ACTIVE_INST_LDS'] / bc:.2f}")
             w(f"   -> wait-any share of wave cycles {v['SQ_WAIT_INST_ANY'] / wc:.2f};  wait-LDS share {v['SQ_WAIT_INST_LDS'] / wc:.2f}")
             w(f"   -> per wave: {v['SQ_INSTS_VALU'] / v['SQ_WAVES']:.0f} VALU, {v['SQ_INSTS_MFMA'] / v['SQ_WAVES']:.0f} MFMA, {v['SQ_INSTS_LDS'] / v['SQ_WAVES']:.0f} LDS instructions;  "
