@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: tools_prof.sh <tag>   (runs on the GPU box via gpurun; prints the per-kernel summary)
 TAG=$1
-/usr/local/graft/bin/gpurun --timeout 900 -- "mkdir -p gpurun_out/prof_$TAG && cd /tmp && export TMPDIR=/tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d \$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG -- python3 \$GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-highest --no-kernel-timer > \$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG/bench.out 2>&1; tail -c 600 \$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG/bench.out" 2>&1 | tail -4
+/usr/local/graft/bin/gpurun --timeout 900 -- "mkdir -p gpurun_out/prof_$TAG && cd /tmp && export TMPDIR=/tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d \$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG -- python3 \$GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-highest --no-kernel-timer --no-extra-configs > \$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG/bench.out 2>&1; tail -c 600 \$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG/bench.out" 2>&1 | tail -4
 python3 - <<PY
 import csv,glob
 import os; f=max(glob.glob("gpurun_out/prof_$TAG/*/*_kernel_stats.csv"), key=os.path.getmtime)
