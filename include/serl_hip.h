@@ -220,6 +220,10 @@ int serl_tanh_gaussian_fwd(const float* mean, const float* log_std_raw, int ld_m
 int serl_tanh_gaussian_bwd(const float* act, int ld_act, const float* eps, const float* log_std_raw, int ld_ms,
                            const float* da, int ld_da, const float* log_temp, float inv_batch, float* dmean,
                            float* dlstd, int ld_out, int B, int A, void* stream);
+/* log pi(a) of GIVEN actions (B, A): TanhTransformedDistribution.log_prob (serl/distributions/tanh_transformed.py:17-30)
+ * with the Tanh bijector's float32 inverse atanh(clip(a, +-nextafter(1, 0))); logp (B). */
+int serl_tanh_gaussian_log_prob(const float* mean, const float* log_std_raw, int ld_ms, const float* actions, int ld_act,
+                                float* logp, int B, int A, void* stream);
 /* Ensemble(StateActionValue(MLP)) forward with hidden dims (256, 256) in ONE launch (csrc/ensemble.hip; serl/networks/
  * ensemble.py:8-22, state_action_value.py:11-19, mlp.py:18-35): Dense -> [LayerNorm] -> ReLU twice, then the Dense(1) head.
  * Member e's leaves sit e * stride floats behind the given pointers (a negative stride walks a REDQ subsample backwards).

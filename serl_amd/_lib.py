@@ -48,6 +48,7 @@ _SIGS = {
     "serl_tanh_gaussian_nll": [c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_f, c_p, c_p, c_i, c_p, c_p],
     "serl_bce_logits": [c_p, c_p, c_i, c_i, c_f, c_p, c_p, c_p],
     "serl_ensemble_fwd_fused": [c_p, c_i, c_i, c_i, c_i] + [c_p] * 10 + [c_ll] * 4 + [c_i] + [c_p] * 8,
+    "serl_tanh_gaussian_log_prob": [c_p, c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_p],
     "serl_ensemble_fwd_fused_pair": [c_p, c_p, c_p],
     "serl_policy_fwd_fused": [c_p, c_i, c_i, c_i] + [c_p] * 8 + [c_i, c_u, c_u, c_i, c_i, c_i, c_p, c_i] + [c_p] * 6,
     "serl_ensemble_bwd_fused": [c_p, c_i, c_i] + [c_p] * 4 + [c_i] + [c_p] * 11,

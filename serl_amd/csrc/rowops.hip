@@ -573,6 +573,33 @@ extern "C" int serl_tanh_gaussian_nll(const float* mean, const float* log_std_ra
   return SERL_OK;
 }
 
+// log pi(a) of GIVEN actions under the tanh-Gaussian, one thread per row: TanhTransformedDistribution.log_prob
+// (serl/distributions/tanh_transformed.py:17-30 over tanh_normal.py:41-48): x = atanh(clip(a, +-nextafter(1, 0))) -- the
+// Tanh bijector's inverse in float32 -- then the diagonal-normal log-density minus the Tanh log-det-Jacobian.
+__global__ void tanh_gaussian_log_prob_kernel(const float* mean, const float* lstd, int ld_ms, const float* act, int ld_act,
+                                              float* logp, int B, int A) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float lp = 0.f;
+  for (int j = 0; j < A; ++j) {
+    const float a = fminf(fmaxf(act[(long long)b * ld_act + j], -0.99999994f), 0.99999994f);
+    const float x = atanhf(a);
+    const float mu = mean[(long long)b * ld_ms + j];
+    const float ls = fminf(fmaxf(lstd[(long long)b * ld_ms + j], -20.f), 2.f);
+    const float z = (x - mu) * expf(-ls);
+    lp += (-0.5f * z * z - ls - 0.918938533204672742f) - 2.f * (0.693147180559945309f - x - softplusf(-2.f * x));
+  }
+  logp[b] = lp;
+}
+extern "C" int serl_tanh_gaussian_log_prob(const float* mean, const float* log_std_raw, int ld_ms, const float* actions,
+                                           int ld_act, float* logp, int B, int A, void* stream) {
+  SERL_CHECK_ARG(mean && log_std_raw && actions && logp && B >= 1 && A >= 1 && ld_ms >= A && ld_act >= A, "tanh_gaussian_log_prob: bad args");
+  hipLaunchKernelGGL(tanh_gaussian_log_prob_kernel, dim3(cdiv(B, 64)), dim3(64), 0, (hipStream_t)stream, mean, log_std_raw, ld_ms,
+                     actions, ld_act, logp, B, A);
+  SERL_CHECK_LAUNCH("tanh_gaussian_log_prob");
+  return SERL_OK;
+}
+
 // optax.sigmoid_binary_cross_entropy(logits, labels).mean() with labels = (a > 0) of one action column
 // (pixel_hybrid_bc_learner.py:167-176): l = -y log_sigmoid(x) - (1 - y) log_sigmoid(-x) = max(x, 0) - x y + log1p(exp(-|x|)),
 // dl/dx = sigmoid(x) - y.  info[0] = sum_b l_b, dlogit = dl/dx / Bg.

@@ -896,3 +896,38 @@ def test_gpu_replay_buffer_matches_oracle():
     rb2.upload(blk(10))
     mx, batch = rb2.sample_jax(5)
     assert int(mx) == op.randint(op.split(op.prng_key(42))[0], (5,), 0, 10).max()
+
+
+def test_tanh_normal_distribution_object(dev):
+    """serl_amd.distributions.TanhNormal -- the object the reference's actor apply_fn returns
+    (serl/distributions/tanh_normal.py:17-53, tanh_transformed.py:17-30): sample(seed) on the jax.random.normal stream,
+    log_prob of the sample (cached pre-tanh value) and of arbitrary actions (float32 atanh of the clipped action), mode()."""
+    from oracle import learner as ol, prng
+    from serl_amd.distributions import TanhNormal
+    rng = np.random.default_rng(9)
+    B, A = 37, 7
+    mean = rng.standard_normal((B, A)).astype(np.float32)
+    raw = (rng.standard_normal((B, A)) * 2).astype(np.float32)
+    raw[0, 0], raw[1, 1] = 4.0, -30.0                      # clipped log-stds
+    d = TanhNormal(dv(mean, dev), dv(raw, dev))
+    assert d.batch_shape == (B,) and d.event_shape == (A,)
+    key = prng.split(prng.prng_key(11))[1]
+    a = d.sample(seed=key)
+    m32, l32 = torch.tensor(mean), torch.clamp(torch.tensor(raw), -20.0, 2.0)
+    oa, ox = ol.tanh_normal_sample(m32, l32, key)
+    close(a.cpu().numpy(), oa.numpy(), rtol=2e-6, what="sample")
+    close(d.log_prob(a).cpu().numpy(), ol.tanh_normal_log_prob(m32, l32, ox).numpy(), rtol=1e-5, what="log_prob of the sample")
+    close(d.mode().cpu().numpy(), np.tanh(mean.astype(np.float64)), rtol=2e-6, what="mode")
+    # arbitrary actions, incl. +-1 (the bijector clips before atanh)
+    acts = rng.uniform(-0.999, 0.999, (B, A)).astype(np.float32)
+    acts[2, 3], acts[3, 0] = 1.0, -1.0
+    clipped = np.clip(acts.astype(np.float64), -float(np.float32(0.99999994)), float(np.float32(0.99999994)))
+    x = torch.tensor(np.arctanh(clipped))
+    want = ol.tanh_normal_log_prob(m32.double(), l32.double(), x).numpy()
+    got = d.log_prob(dv(acts, dev)).cpu().numpy()
+    # rows holding a clipped +-1 action sit on atanh's pole in float32: compare those loosely
+    edge = (np.abs(acts) == 1).any(1)
+    close(got[~edge], want[~edge], rtol=2e-5, what="log_prob of given actions")
+    assert np.all(np.isfinite(got)) and np.abs(got[edge] - want[edge]).max() < 1.0
+    a2, lp2 = d.sample_and_log_prob(key)
+    assert torch.equal(a2, a) and torch.equal(lp2, d.log_prob(a2))
