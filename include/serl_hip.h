@@ -96,6 +96,21 @@ int serl_convs_dgrad(int ngroups, const void* const* dz, const void* const* wd, 
 int serl_convs_wgrad(int ngroups, const void* const* x, const void* const* dz, float* const* dw, float* const* dbias,
                      float* workspace, long long workspace_bytes, int in_u8, int B, int IH, int IW, int C, int KH,
                      int KW, int stride, int F, void* stream);
+/* conv2's data gradient and conv1's weight + bias gradient in ONE launch (the backward of two_d4pg_encoder.py:30-38's
+ * first two layers): conv1 reads the uint8 frames, so dz1 = ReLU'(act1) * dgrad(conv2)(dz2) is needed by conv1's weight
+ * gradient only; here it goes from the data gradient's accumulators into the weight-gradient MFMAs and is never written
+ * to memory (0.26 GB per 2-camera step at the headline size).  dz2 / wd2 as for serl_convs_dgrad of layer 2 (3x3
+ * stride 2, 32 -> 64), rmask1 = the ReLU byte mask serl_convs_fwd wrote for layer 1 (or NULL: no mask), frames uint8
+ * [B][IH1][IW1][C1]; dw1 (3,3,C1,32) and dbias1 (32) get the gradient of serl_convs_fwd(in_u8 = 1) (incl. its 1/255).
+ * Replaces serl_convs_dgrad + serl_convs_wgrad(in_u8 = 1): the same dz1 bits go into the products, the fp32 sums run in
+ * another order.  workspace: serl_convs_dgrad_wgrad1_workspace_bytes(ngroups) bytes are always enough.
+ * serl_convs_dgrad_wgrad1_supported returns 1 when the geometry fits (C1 = 9, F1 = 32, F2 = 64, IW1 * C1 a multiple of 16,
+ * conv1's output at most 64 wide) and the patch kernels are enabled. */
+int serl_convs_dgrad_wgrad1_supported(int IH1, int IW1, int C1, int F1, int F2);
+long long serl_convs_dgrad_wgrad1_workspace_bytes(int ngroups);
+int serl_convs_dgrad_wgrad1(int ngroups, const void* const* dz2, const void* const* wd2, const void* const* rmask1,
+                            const void* const* frames_u8, float* const* dw1, float* const* dbias1, float* workspace,
+                            long long workspace_bytes, int B, int IH1, int IW1, int C1, int F1, int F2, void* stream);
 /* serl_convs_wgrad without a workspace argument and without any allocation.  NO COUNTERPART IN THE REFERENCE: it is for
  * callers that cannot call hipMalloc -- code under HIP graph capture, tight serving loops, harnesses that forbid it.
  * The split-K slabs live in a 64 MiB file-scope device array of the library (one copy per GPU, held until the process

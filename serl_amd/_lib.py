@@ -73,6 +73,9 @@ _SIGS = {
     "serl_convs_set_cu_limit": [c_i],
     "serl_convs_fwd12_supported": [c_i, c_i, c_i, c_i, c_i],
     "serl_convs_fwd12": [c_i, PP, PP, PP, PP, PP, PP, c_i, c_i, c_i, c_i, c_i, c_i, c_i, PP, c_p],
+    "serl_convs_dgrad_wgrad1_supported": [c_i, c_i, c_i, c_i, c_i],
+    "serl_convs_dgrad_wgrad1_workspace_bytes": [c_i],
+    "serl_convs_dgrad_wgrad1": [c_i, PP, PP, PP, PP, PP, PP, c_p, c_ll, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "serl_gather_crop_frames": [c_p, c_ll, c_p, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
     "serl_gather_crop_packed": [c_p, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
     "serl_gather_window": [c_p, c_ll, c_p, c_p, c_i, c_i, c_i, c_p],
@@ -115,7 +118,7 @@ _SIGS = {
 }
 _RESTYPE = {"serl_conv2d_wgrad_workspace_bytes": c_ll, "serl_convs_weight_bytes": c_ll,
             "serl_convs_wgrad_noalloc_max_bytes": c_ll, "serl_learner_workspace_bytes": c_ll, "serl_mbv3_param_floats": c_ll,
-            "serl_mbv3_workspace_bytes": c_ll}
+            "serl_mbv3_workspace_bytes": c_ll, "serl_convs_dgrad_wgrad1_workspace_bytes": c_ll}
 
 EXPORTS = tuple(_SIGS) + ("serl_last_error",)
 
@@ -146,7 +149,7 @@ def load():
     lib.serl_last_error.argtypes = []
     lib.serl_last_error.restype = C.c_char_p
     _lib = lib
-    if os.environ.get("SERL_AMD_CONV_PATCH") in ("0", "2", "3", "4"):   # A/B measurements (serl_convs_set_patch_kernels)
+    if os.environ.get("SERL_AMD_CONV_PATCH") in ("0", "2", "3", "4", "5"):   # A/B measurements (serl_convs_set_patch_kernels)
         lib.serl_convs_set_patch_kernels(int(os.environ["SERL_AMD_CONV_PATCH"]))
     env = os.environ.get("SERL_AMD_MATMUL_PRECISION")
     if env is not None:

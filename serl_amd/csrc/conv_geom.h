@@ -90,7 +90,12 @@ static void wgrad_plan(const ConvGeom& g, int ngroups, int& nsplit, int& klen) {
   const int kkc1 = g.KH * g.KW * g.C + 1;
   const int bn = g.F <= 32 ? 32 : (g.F <= 64 ? 64 : 128);
   const int tiles = cdiv(kkc1, 128) * cdiv(g.F, bn) * ngroups;
-  int want = cdiv(WGRAD_BLOCKS, tiles);
+  static const int deep_blocks = [] {
+    const char* e = getenv("SERL_AMD_WGRAD_BLOCKS_DEEP");
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? v : WGRAD_BLOCKS;
+  }();
+  int want = cdiv(kkc1 > 512 ? deep_blocks : WGRAD_BLOCKS, tiles);
   if (want < 1) want = 1;
   klen = cdiv(cdiv(Kr, want), 64) * 64;   // multiple of every kernel's K slab
   if (klen < 64) klen = 64;

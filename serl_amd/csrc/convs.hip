@@ -9,6 +9,7 @@
 #include "conv_geom.h"
 #include "sgemm.h"
 #include "pconv.h"
+#include "pconv_dgw1.h"
 #include "sgemm_ring.h"
 
 typedef unsigned short ushort_t;
@@ -583,12 +584,14 @@ extern "C" int serl_convs_prep_weights_multi(int njobs, const float* const* w, v
 // kernel takes.  The ring GEMM is 5-8 % faster than the register-staged kernel stand-alone but takes the CU's whole LDS
 // (one block per CU), so nothing of the other streams runs next to it: -1 % on the whole update, hence not the default.
 // 4 = as 1 with the one-set fused layers-1+2 kernel (pconv_fused12_kernel) instead of the two-set one.
-static int g_patch_kernels = 1, g_ring_kernels = 0, g_wide_kernels = 1, g_f12_two_sets = 1;
+// 5 = as 1 without the fused conv2-data-gradient + conv1-weight-gradient kernel (serl_convs_dgrad_wgrad1_supported says 0).
+static int g_patch_kernels = 1, g_ring_kernels = 0, g_wide_kernels = 1, g_f12_two_sets = 1, g_dgw1 = 1;
 extern "C" int serl_convs_set_patch_kernels(int enable) {
   g_patch_kernels = enable ? 1 : 0;
   g_ring_kernels = enable == 3 ? 1 : 0;
   g_wide_kernels = enable == 1 || enable == 3 || enable == 4 ? 1 : 0;
   g_f12_two_sets = enable == 4 ? 0 : 1;
+  g_dgw1 = enable == 5 ? 0 : 1;
   return SERL_OK;
 }
 
@@ -754,6 +757,55 @@ extern "C" int serl_convs_dgrad(int ngroups, const void* const* dz, const void* 
   }
   const int max_m = g.B * cdiv(g.IH, stride) * cdiv(g.IW, stride);
   return s_launch_by_n(S_DGRAD, p, max_m, g.C, 1, ngroups * stride * stride, (hipStream_t)stream, "convs_dgrad");
+}
+
+// conv2's data gradient and conv1's weight + bias gradient in one launch (pconv_dgw1.h): dz1 = mask * dgrad(dz2) is used as
+// it leaves the accumulators and never reaches HBM.  Replaces serl_convs_dgrad(layer 2) + serl_convs_wgrad(in_u8 = 1,
+// layer 1): same dz1 bits, dW1 / dbias1 equal to the separate kernels' up to the order of the fp32 sums.
+extern "C" int serl_convs_dgrad_wgrad1_supported(int IH1, int IW1, int C1, int F1, int F2) {
+  return g_patch_kernels && g_dgw1 && pconv_dgw1_fits(IH1, IW1, C1, F1, F2) ? 1 : 0;
+}
+extern "C" long long serl_convs_dgrad_wgrad1_workspace_bytes(int ngroups) {
+  return (long long)ngroups * 1024 * PDgw1Cfg::SLAB * 4;      // one slab per block, at most 1024 blocks per group
+}
+extern "C" int serl_convs_dgrad_wgrad1(int ngroups, const void* const* dz2, const void* const* wd2,
+                                       const void* const* rmask1, const void* const* frames_u8, float* const* dw1,
+                                       float* const* dbias1, float* workspace, long long workspace_bytes, int B, int IH1,
+                                       int IW1, int C1, int F1, int F2, void* stream) {
+  SERL_CHECK_ARG(ngroups >= 1 && ngroups <= MAXG, "convs_dgrad_wgrad1: ngroups must be in [1,%d]", MAXG);
+  SERL_CHECK_ARG(B > 0 && pconv_dgw1_fits(IH1, IW1, C1, F1, F2),
+                 "convs_dgrad_wgrad1: geometry %dx%dx%d -> %d -> %d does not fit the fused kernel (serl_convs_dgrad_wgrad1_supported)",
+                 IH1, IW1, C1, F1, F2);
+  SERL_CHECK_ARG((long long)B * IH1 * IW1 * C1 < (1ll << 31), "convs_dgrad_wgrad1: tensor exceeds 2^31 elements");
+  SERL_CHECK_ARG(all_aligned16(dz2, ngroups) && all_aligned16(wd2, ngroups) && all_aligned16(frames_u8, ngroups),
+                 "convs_dgrad_wgrad1: dz, weights and frames must be 16-byte aligned");
+  SERL_CHECK_ARG(workspace != nullptr, "convs_dgrad_wgrad1: workspace missing");
+  bool uniform = true;                  // the byte mask is given for every group or for none
+  if (rmask1 != nullptr)
+    for (int i = 0; i < ngroups; ++i) uniform = uniform && ((rmask1[i] != nullptr) == (rmask1[0] != nullptr));
+  SERL_CHECK_ARG(uniform, "convs_dgrad_wgrad1: the ReLU mask must be given for every group or for none");
+  PConvDgw1Args a;
+  a.B = B; a.IH1 = IH1; a.rb1 = IW1 * C1; a.scale = 1.0f / 255.0f;
+  a.IH = (IH1 - 3) / 2 + 1; a.IW = (IW1 - 3) / 2 + 1;
+  a.OH = (a.IH - 3) / 2 + 1; a.OW = (a.IW - 3) / 2 + 1;
+  a.nbands = cdiv((a.IH + 1) / 2, PDgw1Cfg::P);
+  a.d_bands = make_fastdiv(a.nbands);
+  a.slab = workspace;
+  for (int i = 0; i < ngroups; ++i) {
+    SERL_CHECK_ARG(dw1[i] && dbias1[i], "convs_dgrad_wgrad1: null gradient output");
+    a.dz[i] = (const ushort_t*)dz2[i]; a.wd[i] = (const ushort_t*)wd2[i];
+    a.xbits[i] = rmask1 ? (const unsigned char*)rmask1[i] : nullptr;
+    a.img[i] = (const unsigned char*)frames_u8[i];
+  }
+  int nslab = 0;
+  if (int e = pconv_dgw1_launch(a, ngroups, workspace_bytes, &nslab, (hipStream_t)stream, "convs_dgrad_wgrad1")) return e;
+  SERL_CHECK_ARG(nslab > 0, "convs_dgrad_wgrad1: the workspace (%lld bytes) cannot hold the slabs (serl_convs_dgrad_wgrad1_workspace_bytes)",
+                 workspace_bytes);
+  ReduceArgs ra; ra.slab = workspace; ra.nsplit = nslab; ra.kkc = 9 * C1; ra.F = F1;
+  for (int i = 0; i < ngroups; ++i) { ra.dw[i] = dw1[i]; ra.db[i] = dbias1[i]; }
+  launch_wgrad_reduce(ra, ngroups, (hipStream_t)stream);
+  SERL_CHECK_LAUNCH("wgrad_reduce");
+  return SERL_OK;
 }
 
 static int convs_wgrad_impl(const char* name, int ngroups, const void* const* x, const void* const* dz,

@@ -271,6 +271,7 @@ struct serl_learner {
   bool ens_fused = getenv("SERL_AMD_ENS_FUSED") == nullptr || strcmp(getenv("SERL_AMD_ENS_FUSED"), "0") != 0;   // A/B switch
   bool pol_fused = getenv("SERL_AMD_POL_FUSED") == nullptr || strcmp(getenv("SERL_AMD_POL_FUSED"), "0") != 0;   // A/B switch
   bool ens_bwd_fused = getenv("SERL_AMD_ENS_BWD_FUSED") == nullptr || strcmp(getenv("SERL_AMD_ENS_BWD_FUSED"), "0") != 0;   // A/B switch
+  bool fuse_dgw1 = getenv("SERL_AMD_CONV_DGW1") == nullptr || strcmp(getenv("SERL_AMD_CONV_DGW1"), "0") != 0;   // A/B switch
   bool fuse12 = getenv("SERL_AMD_CONV_FUSE12") == nullptr || strcmp(getenv("SERL_AMD_CONV_FUSE12"), "0") != 0;   // A/B switch
   std::vector<TimeRec> trecs;
   std::vector<PhaseRec> precs;
@@ -339,6 +340,13 @@ void conv_cost(int kind, int in_u8, int n, int B, const ConvL& L, double* flops,
     const int oh2 = (L.OH - 3) / 2 + 1, ow2 = (L.OW - 3) / 2 + 1, f2 = 64;
     *flops += 2.0 * n * B * oh2 * ow2 * f2 * 9.0 * L.F;
     *bytes = x + w + (double)n * 9 * L.F * f2 * 4 + (double)n * B * oh2 * ow2 * f2 * 4 + n * (L.F + f2) * 4.0;
+    return;
+  }
+  if (kind == 4) {   // conv2's data gradient + conv1's weight gradient fused (L = layer 1): dz2, byte mask and frames in, dW1 out
+    const int oh2 = (L.OH - 3) / 2 + 1, ow2 = (L.OW - 3) / 2 + 1, f2 = 64;
+    *flops += 2.0 * n * B * oh2 * ow2 * f2 * 9.0 * L.F;
+    *bytes = x + (double)n * B * oh2 * ow2 * f2 * 4 + (double)n * B * L.OH * L.OW * L.F / 8 + (double)n * 9 * L.F * f2 * 4 + w +
+             n * L.F * 4.0;
     return;
   }
   if (kind == 0) *bytes = x + w + y + n * L.F * 4.0;
@@ -545,9 +553,15 @@ int encoder_bwd(serl_learner* h, char tag, const Store& store, const EncOff& eo,
     SERL_CHECK_ARG(b >= 0, "learner: bad conv geometry in layer %d", li);
     slab_bytes = std::max(slab_bytes, b);
   }
+  // conv2's data gradient and conv1's weight gradient in one launch (serl_convs_dgrad_wgrad1): dz1 stays on chip
+  const bool dgw1_fits = split && nl >= 2 && c.L[0].K == 3 && c.L[0].S == 2 && c.L[1].K == 3 && c.L[1].S == 2 &&
+                         serl_convs_dgrad_wgrad1_supported(c.L[0].IH, c.L[0].IW, c.L[0].C, c.L[0].F, c.L[1].F);
+  const bool dgw1 = dgw1_fits && use_masks && h->fuse_dgw1;
+  if (dgw1_fits) slab_bytes = std::max(slab_bytes, serl_convs_dgrad_wgrad1_workspace_bytes(ncam));   // (one size per name)
   WSF(ws, st, slab, (size_t)slab_bytes / 4, "wgrad_slab");
   for (int li = nl - 1; li >= 0; --li) {
     const ConvL& L = c.L[li];
+    if (li == 0 && dgw1) break;     // done by the fused launch of layer 2's data gradient
     const void* dz[MAX_CAM]; const void* xs[MAX_CAM]; float* dw[MAX_CAM]; float* db[MAX_CAM];
     for (int ci = 0; ci < ncam; ++ci) {
       WSF(ws, st, d, (size_t)B * L.OH * L.OW * L.F, "dact%d_%d", li, ci);
@@ -590,7 +604,28 @@ int encoder_bwd(serl_learner* h, char tag, const Store& store, const EncOff& eo,
                               L.K, L.K, L.S, L.F, sw));
       DRV(t.end());
     }
-    if (li > 0) {
+    if (li == 1 && dgw1) {
+      const ConvL& P = c.L[0];
+      const void* wds[MAX_CAM]; const void* rm[MAX_CAM]; const void* fr[MAX_CAM]; float* dw0[MAX_CAM]; float* db0[MAX_CAM];
+      for (int ci = 0; ci < ncam; ++ci) {
+        WSF(ws, st, wd, (size_t)L.K * L.K * L.C * L.F, "wd%d_%c_%d", li, tag, ci);
+        wds[ci] = wd;
+        WSF(ws, st, r, rmask_floats(B, P), "rmask%d_%c_%d", 0, tag, ci);
+        rm[ci] = r;
+        fr[ci] = imgs[ci];
+        dw0[ci] = grads.at(eo.ck[ci][0]);
+        db0[ci] = grads.at(eo.cb[ci][0]);
+      }
+      float* slab_f = slab;
+      if (gside) {                    // the side streams' weight gradients are using `slab`
+        WSF(ws, st, slab1, (size_t)slab_bytes / 4, "wgrad_slab_main");
+        slab_f = slab1;
+      }
+      Timed t{h, st};
+      DRV(t.begin(4, 1, ncam, B, P));
+      DRV(serl_convs_dgrad_wgrad1(ncam, dz, wds, rm, fr, dw0, db0, slab_f, slab_bytes, B, P.IH, P.IW, P.C, P.F, L.F, st));
+      DRV(t.end());
+    } else if (li > 0) {
       const ConvL& P = c.L[li - 1];
       void* dx[MAX_CAM];
       for (int ci = 0; ci < ncam; ++ci) {
@@ -1886,7 +1921,7 @@ extern "C" int serl_learner_set_timing(serl_learner* h, int conv_events, int pha
   return SERL_OK;
 }
 extern "C" int serl_learner_timing_count(serl_learner* h) { return h ? (int)h->trecs.size() : 0; }
-// record i -> desc[7] = {kind (0 fwd, 1 dgrad, 2 wgrad), in_u8, groups, B, IH, C, F}, val[3] = {ms, flops, bytes};
+// record i -> desc[7] = {kind (0 fwd, 1 dgrad, 2 wgrad, 3 fused layers 1+2 fwd, 4 conv2 dgrad + conv1 wgrad), in_u8, groups, B, IH, C, F}, val[3] = {ms, flops, bytes};
 // call after a device synchronise.
 extern "C" int serl_learner_timing_get(serl_learner* h, int i, int* desc, double* val) {
   SERL_CHECK_ARG(h && desc && val && i >= 0 && i < (int)h->trecs.size(), "learner_timing_get: bad index");

@@ -715,8 +715,10 @@ __global__ __launch_bounds__(512, 1) void pconv_dgrad_kernel(const PConvDgradArg
   if (it0 >= it1) return;
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
-  const int iyl = wid >> 1;                 // row pair of the band
-  const bool type_x = (wid & 1) == 0;       // class (0,0) | classes (0,1), (1,0), (1,1)
+  // waves w and w + 4 share a SIMD: one wave of each type per SIMD (48 + 60 MFMAs per item on each of the four; with
+  // the types alternating by wave the SIMDs got 96 or 120: 120.6 -> 118.5 us stand-alone)
+  const int iyl = wid & 3;                  // row pair of the band
+  const bool type_x = wid < 4;              // class (0,0) | classes (0,1), (1,0), (1,1)
   float* const Cs = reinterpret_cast<float*>(p_smem + 2 * G::PATCH + wid * G::CSB);
   const uint32_t cs_base = (uint32_t)(size_t)(pconv_lptr_t)Cs;
 

@@ -122,6 +122,25 @@ def convs_dgrad(dzs, wds, xacts, dxs, B, IH, IW, C, KH, KW, stride, F, stream, x
     call("serl_convs_dgrad", n, pz, pw, pa, pd, B, IH, IW, C, KH, KW, stride, F, int(xact_bits), stream)
 
 
+def convs_dgrad_wgrad1_supported(IH1, IW1, C1, F1, F2):
+    from ._lib import load
+    return bool(load().serl_convs_dgrad_wgrad1_supported(IH1, IW1, C1, F1, F2))
+
+
+def convs_dgrad_wgrad1_workspace_bytes(ngroups):
+    from ._lib import load
+    return int(load().serl_convs_dgrad_wgrad1_workspace_bytes(ngroups))
+
+
+def convs_dgrad_wgrad1(dz2s, wd2s, rmask1s, frames, dw1s, db1s, workspace, workspace_bytes, B, IH1, IW1, C1, F1, F2, stream):
+    """conv2's data gradient + conv1's weight / bias gradient in one launch: dz1 never reaches HBM."""
+    n = len(dz2s)
+    pz, kz = ptr_table(dz2s); pw, kw = ptr_table(wd2s)
+    pm, km = ptr_table(rmask1s) if rmask1s is not None else (None, None)
+    pf, kf = ptr_table(frames); pdw, kdw = ptr_table(dw1s); pdb, kdb = ptr_table(db1s)
+    call("serl_convs_dgrad_wgrad1", n, pz, pw, pm, pf, pdw, pdb, workspace, workspace_bytes, B, IH1, IW1, C1, F1, F2, stream)
+
+
 def convs_wgrad(xs, dzs, dws, dbs, workspace, workspace_bytes, in_u8, B, IH, IW, C, KH, KW, stride, F, stream):
     n = len(xs)
     px, kx = ptr_table(xs); pz, kz = ptr_table(dzs); pw, kw = ptr_table(dws); pb, kb = ptr_table(dbs)

@@ -302,6 +302,70 @@ def test_patch_conv_bit_identical_to_im2col(dev, case):
             np.testing.assert_allclose(b_, a_, rtol=0, atol=2e-5 * max(1.0, float(np.abs(a_).max())))
 
 
+@pytest.mark.parametrize("masked", [True, False])
+@pytest.mark.parametrize("case", [(3, 128, 128), (2, 100, 128), (1, 7, 16), (2, 34, 32), (40, 128, 128), (70, 36, 48)])
+def test_dgrad_wgrad1_fused_matches_two_launches(dev, case, masked):
+    """serl_convs_dgrad_wgrad1 (conv2's data gradient and conv1's weight + bias gradient in one kernel, dz1 kept on chip)
+    against serl_convs_dgrad followed by serl_convs_wgrad(in_u8): the same dz1 bits enter the products, the fp32 sums run
+    in another order (one slab per persistent block) -> 2e-5 of the largest entry, and bit-identical when repeated.  Full
+    and ragged bands, an image smaller than one band, widths whose last column pair is half empty, batches large enough
+    that a block walks several items, with and without the ReLU byte mask."""
+    ops = _ops()
+    B, IH1, IW1 = case
+    C1, F1, F2, K, S, G = 9, 32, 64, 3, 2, 3
+    assert ops.convs_dgrad_wgrad1_supported(IH1, IW1, C1, F1, F2)
+    assert not ops.convs_dgrad_wgrad1_supported(IH1, IW1, 3, F1, F2) and not ops.convs_dgrad_wgrad1_supported(IH1, IW1 + 1, C1, F1, F2)
+    rng = np.random.default_rng(23)
+    st = ops.current_stream()
+    IH, IW = (IH1 - K) // S + 1, (IW1 - K) // S + 1
+    OH, OW = (IH - K) // S + 1, (IW - K) // S + 1
+    frames, wds, keep, dzs, rms = [], [], [], [], []
+    for g in range(G):
+        frames.append(dv(rng.integers(0, 256, (B, IH1, IW1, C1), dtype=np.uint8), dev))
+        keep.append(dv((rng.standard_normal((K, K, F1, F2)) * 0.1).astype(np.float32), dev))
+        wds.append(torch.full((K * K * F1 * F2 * 2,), -1, dtype=torch.int16, device=dev))
+        buf, _ = _to_s(ops, dv(rng.standard_normal((B, OH, OW, F2)).astype(np.float32), dev), B * OH * OW, F2, st)
+        dzs.append(buf)
+        act = rng.random((B * IH * IW, F1)) < 0.6
+        rms.append(dv(np.packbits(act, axis=1, bitorder="little").reshape(-1), dev))
+    wfs = [torch.empty(ops.convs_weight_bytes(False, K, K, F1, F2) // 2, dtype=torch.int16, device=dev) for _ in range(G)]
+    ops.convs_prep_weights([t.data_ptr() for t in keep], [t.data_ptr() for t in wfs], [t.data_ptr() for t in wds],
+                           False, K, K, F1, F2, st)
+    masks = [t.data_ptr() for t in rms] if masked else None
+    # reference: two launches, dz1 through memory
+    dz1 = [torch.full((B * IH * IW * F1 * 2,), -1, dtype=torch.int16, device=dev) for _ in range(G)]
+    ops.convs_dgrad([t.data_ptr() for t in dzs], [t.data_ptr() for t in wds], masks if masked else [0] * G,
+                    [t.data_ptr() for t in dz1], B, IH, IW, F1, K, K, S, F2, st, xact_bits=masked)
+    dw_ref = [torch.full((K, K, C1, F1), float("nan"), device=dev) for _ in range(G)]
+    db_ref = [torch.full((F1,), float("nan"), device=dev) for _ in range(G)]
+    wsb = ops.conv2d_wgrad_workspace_bytes(G, B, IH1, IW1, C1, K, K, S, F1)
+    wsp = torch.empty(wsb // 4, device=dev)
+    ops.convs_wgrad([t.data_ptr() for t in frames], [t.data_ptr() for t in dz1], [t.data_ptr() for t in dw_ref],
+                    [t.data_ptr() for t in db_ref], wsp.data_ptr(), wsb, True, B, IH1, IW1, C1, K, K, S, F1, st)
+    outs = []
+    wsb2 = ops.convs_dgrad_wgrad1_workspace_bytes(G)
+    for rep in range(2):
+        dw = [torch.full((K, K, C1, F1), float("nan"), device=dev) for _ in range(G)]
+        db = [torch.full((F1,), float("nan"), device=dev) for _ in range(G)]
+        wsp2 = torch.full((wsb2 // 4,), float("nan"), device=dev)
+        ops.convs_dgrad_wgrad1([t.data_ptr() for t in dzs], [t.data_ptr() for t in wds], masks, [t.data_ptr() for t in frames],
+                               [t.data_ptr() for t in dw], [t.data_ptr() for t in db], wsp2.data_ptr(), wsb2, B, IH1, IW1,
+                               C1, F1, F2, st)
+        torch.cuda.synchronize()
+        outs.append((dw, db))
+    for g in range(G):
+        assert torch.equal(outs[0][0][g], outs[1][0][g]) and torch.equal(outs[0][1][g], outs[1][1][g]), "not repeatable"
+        for a_, b_ in ((dw_ref[g], outs[0][0][g]), (db_ref[g], outs[0][1][g])):
+            a_, b_ = a_.cpu().numpy(), b_.cpu().numpy()
+            assert np.isfinite(b_).all()
+            np.testing.assert_allclose(b_, a_, rtol=0, atol=2e-5 * max(1.0, float(np.abs(a_).max())))
+    # too small a workspace is refused, not overrun
+    with pytest.raises(ValueError):
+        ops.convs_dgrad_wgrad1([t.data_ptr() for t in dzs], [t.data_ptr() for t in wds], masks, [t.data_ptr() for t in frames],
+                               [t.data_ptr() for t in outs[0][0]], [t.data_ptr() for t in outs[0][1]], wsp2.data_ptr(), 1024,
+                               B, IH1, IW1, C1, F1, F2, st)
+
+
 @pytest.mark.parametrize("mode", [1, 4])        # two wave sets half a period apart (default) / one set
 @pytest.mark.parametrize("case", [(3, 128, 128, 9), (2, 100, 128, 9), (2, 128, 128, 3), (2, 31, 32, 8), (1, 7, 16, 3),
                                   (24, 128, 128, 9), (45, 31, 32, 8), (70, 20, 48, 3)])

@@ -96,4 +96,28 @@ for li, (IH, C, F) in enumerate(LAYERS):
         per_step = ms * (1 if what == "fwd" else 1)
         tot += per_step
         print(f"conv{li + 1} {what:5s} G={G}: {ms * 1e3:8.1f} us  {flop1 * G / ms / 1e9:7.1f} TFLOP/s")
+if MODE == "s" and (not ONLY or "dgw1" in ONLY.split(",")):
+    # conv2's data gradient + conv1's weight gradient in one launch (serl_convs_dgrad_wgrad1) at the headline geometry
+    G, IH1, C1, F1, F2 = 2, 128, 9, 32, 64
+    IH = (IH1 - 3) // 2 + 1; OH = (IH - 3) // 2 + 1
+    p = lambda ts: [t.data_ptr() for t in ts]
+    fr = [torch.randint(0, 256, (B, IH1, IH1, C1), dtype=torch.uint8, device=dev) for _ in range(G)]
+    dzS = []
+    for _ in range(G):
+        z = torch.randn((B, OH, OH, F2), device=dev)
+        buf = torch.empty(z.numel() * 2, dtype=torch.int16, device=dev)
+        ops.split_f32(z.data_ptr(), buf.data_ptr(), B * OH * OH, F2, st)
+        dzS.append(buf)
+    ws2 = [torch.randn((3, 3, F1, F2), device=dev) * 0.05 for _ in range(G)]
+    wf = [torch.empty(ops.convs_weight_bytes(False, 3, 3, F1, F2) // 2, dtype=torch.int16, device=dev) for _ in range(G)]
+    wd = [torch.empty(9 * F1 * F2 * 2, dtype=torch.int16, device=dev) for _ in range(G)]
+    ops.convs_prep_weights(p(ws2), p(wf), p(wd), False, 3, 3, F1, F2, st)
+    bm = [torch.randint(0, 256, (B * IH * IH * F1 // 8,), dtype=torch.uint8, device=dev) for _ in range(G)]
+    dws = [torch.empty((3, 3, C1, F1), device=dev) for _ in range(G)]
+    dbs = [torch.empty(F1, device=dev) for _ in range(G)]
+    nb = ops.convs_dgrad_wgrad1_workspace_bytes(G)
+    wk = torch.empty(nb // 4, device=dev)
+    ms = timeit(lambda: ops.convs_dgrad_wgrad1(p(dzS), p(wd), p(bm), p(fr), p(dws), p(dbs), wk.data_ptr(), nb, B, IH1, IH1, C1, F1, F2, st))
+    flops = 2.0 * G * B * (OH * OH * F2 * 9 * F1 + IH * IH * F1 * 9 * C1)
+    print(f"conv2 dgrad + conv1 wgrad fused (dgw1) G={G}: {ms * 1e3:8.1f} us  {flops / ms / 1e9:7.1f} TFLOP/s")
 print(f"sum of one fwd({FWD_G} groups)+wgrad+dgrad per layer: {tot:.3f} ms per grad-step (ideal {301e9 / 157.3e12 * 1e3:.2f})")
