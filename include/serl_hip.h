@@ -90,6 +90,17 @@ int serl_convs_fwd12_supported(int IH1, int IW1, int C1, int F1, int F2);
 int serl_convs_fwd12(int ngroups, const void* const* x_u8, const void* const* wf1, const float* const* bias1,
                      const void* const* wf2, const float* const* bias2, void* const* y, int B, int IH1, int IW1, int C1,
                      int F1, int F2, int relu, void* const* rmask, void* stream);
+/* serl_convs_fwd12 for the pass whose backward follows (the critic's / the actor's own pass): the groups with
+ * y1[i] != NULL also get layer 1's output (S format [B][IH][IW][32], the bits serl_convs_fwd(in_u8 = 1) stores; rows
+ * 0 .. 2 OH, i.e. every row layer 2 reads) and, with rmask1[i], its ReLU byte mask -- what the weight gradient of layer 2
+ * and serl_convs_dgrad_wgrad1 need.  Layer 1's output is written once from the kernel's LDS patch and not read back by
+ * layer 2 (0.26 GB per 2-camera pass at the headline size).  serl_convs_fwd12_keep_supported: geometry as
+ * serl_convs_fwd12_supported, two-set kernel enabled. */
+int serl_convs_fwd12_keep_supported(int IH1, int IW1, int C1, int F1, int F2);
+int serl_convs_fwd12_keep(int ngroups, const void* const* x_u8, const void* const* wf1, const float* const* bias1,
+                          const void* const* wf2, const float* const* bias2, void* const* y, int B, int IH1, int IW1,
+                          int C1, int F1, int F2, int relu, void* const* rmask, void* const* y1, void* const* rmask1,
+                          void* stream);
 int serl_convs_dgrad(int ngroups, const void* const* dz, const void* const* wd, const void* const* xact,
                      void* const* dx, int B, int IH, int IW, int C, int KH, int KW, int stride, int F, int xact_bits,
                      void* stream);

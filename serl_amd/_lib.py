@@ -73,6 +73,8 @@ _SIGS = {
     "serl_convs_set_cu_limit": [c_i],
     "serl_convs_fwd12_supported": [c_i, c_i, c_i, c_i, c_i],
     "serl_convs_fwd12": [c_i, PP, PP, PP, PP, PP, PP, c_i, c_i, c_i, c_i, c_i, c_i, c_i, PP, c_p],
+    "serl_convs_fwd12_keep_supported": [c_i, c_i, c_i, c_i, c_i],
+    "serl_convs_fwd12_keep": [c_i, PP, PP, PP, PP, PP, PP, c_i, c_i, c_i, c_i, c_i, c_i, c_i, PP, PP, PP, c_p],
     "serl_convs_dgrad_wgrad1_supported": [c_i, c_i, c_i, c_i, c_i],
     "serl_convs_dgrad_wgrad1_workspace_bytes": [c_i],
     "serl_convs_dgrad_wgrad1": [c_i, PP, PP, PP, PP, PP, PP, c_p, c_ll, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
@@ -149,7 +151,7 @@ def load():
     lib.serl_last_error.argtypes = []
     lib.serl_last_error.restype = C.c_char_p
     _lib = lib
-    if os.environ.get("SERL_AMD_CONV_PATCH") in ("0", "2", "3", "4", "5"):   # A/B measurements (serl_convs_set_patch_kernels)
+    if os.environ.get("SERL_AMD_CONV_PATCH") in ("0", "2", "3", "4", "5", "6"):   # A/B measurements (serl_convs_set_patch_kernels)
         lib.serl_convs_set_patch_kernels(int(os.environ["SERL_AMD_CONV_PATCH"]))
     env = os.environ.get("SERL_AMD_MATMUL_PRECISION")
     if env is not None:

@@ -23,26 +23,24 @@ static int make_geom(ConvGeom& g, int B, int IH, int IW, int C, int KH, int KW, 
   return SERL_OK;
 }
 
-// out[g][e] = sum_s slab[g][s][e]; rows < KKC go to dW, the last row to dbias.  Block = 64 lanes x float4 (256
-// consecutive elements: 1 KB coalesced per slab row) x 4 slab lanes; lane sl sums slabs sl, sl+4, ... with independent
-// loads in flight, then the 4 partials are added in a fixed order (reproducible, no atomics).  F % 4 == 0.
+// out[g][e] = sum_s slab[g][s][e]; rows < KKC go to dW, the last row to dbias.
 struct ReduceArgs {
   const float* slab; float* dw[MAXG]; float* db[MAXG];
   int nsplit, kkc, F;
 };
-// Fixed-order sum of the split-K slabs (reproducible, no atomics).  A block = EL element lanes (V consecutive floats each:
-// EL * V * 4 bytes of one slab row, coalesced) x SL slab lanes; slab lane sl sums slabs sl, sl + SL, ... (all its loads are
-// independent and issued together), the SL partial sums are added in lane order through LDS.  SL = 16: the launches reduce
-// 20-60 MB spread over 26-128 slabs, and with 4 slab lanes a thread walked up to 32 slabs as a chain of 4 load batches on
-// 144-1150 blocks (29 us average, 118 us per grad-step over the four layers).
+// Fixed-order sum of the split-K slabs (reproducible, no atomics), without LDS and without a barrier: the launches run
+// next to persistent patch kernels that hold 150 of a CU's 160 KB of LDS, and a block that needs 4 KB of it found room
+// on a CU only one at a time (conv3's 61 MB of slabs: 19 us alone, 84 us inside the update).  A wave = EL = 16 element
+// lanes (V consecutive floats each: 256 bytes of one slab row, coalesced) x 4 slab lanes; slab lane sl sums slabs sl,
+// sl + 4, ... (independent loads, 8 in flight), then the four partial sums are added across the lanes 16 and 32 apart.
 template <int V>
 static __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const ReduceArgs a) {
-  constexpr int SL = 16, EL = 256 / SL;
-  __shared__ float part[SL][EL][V];
+  constexpr int SL = 4, EL = 16;
   const int gi = blockIdx.y;
   const int nel = (a.kkc + 1) * a.F;
-  const int ln = threadIdx.x % EL, sl = threadIdx.x / EL;
-  const int el = (blockIdx.x * EL + ln) * V;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ln = lane & (EL - 1), sl = lane / EL;
+  const int el = ((blockIdx.x * 4 + wave) * EL + ln) * V;
   const float* base = a.slab + (size_t)gi * a.nsplit * (size_t)nel;
   float s[V];
 #pragma unroll
@@ -60,13 +58,11 @@ static __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const ReduceAr
     }
   }
 #pragma unroll
-  for (int j = 0; j < V; ++j) part[sl][ln][j] = s[j];
-  __syncthreads();
+  for (int j = 0; j < V; ++j) {
+    s[j] += __shfl_xor(s[j], 16);
+    s[j] += __shfl_xor(s[j], 32);
+  }
   if (sl == 0 && el < nel) {
-#pragma unroll
-    for (int k = 1; k < SL; ++k)
-#pragma unroll
-      for (int j = 0; j < V; ++j) s[j] += part[k][ln][j];
     float* dst = el < a.kkc * a.F ? a.dw[gi] + el : a.db[gi] + (el - a.kkc * a.F);
     if constexpr (V == 4) *reinterpret_cast<float4*>(dst) = make_float4(s[0], s[1], s[2], s[3]);
     else *dst = s[0];
@@ -78,8 +74,8 @@ static inline void launch_wgrad_reduce(const ReduceArgs& ra, int ngroups, hipStr
   const int nel = (ra.kkc + 1) * ra.F;
   bool v4 = ra.F % 4 == 0 && ((uintptr_t)ra.slab & 15) == 0;
   for (int i = 0; i < ngroups; ++i) v4 = v4 && (((uintptr_t)ra.dw[i] | (uintptr_t)ra.db[i]) & 15) == 0;
-  if (v4) hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3((nel + 63) / 64, ngroups), dim3(256), 0, st, ra);
-  else hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3((nel + 15) / 16, ngroups), dim3(256), 0, st, ra);
+  if (v4) hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3((nel + 255) / 256, ngroups), dim3(256), 0, st, ra);
+  else hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3((nel + 63) / 64, ngroups), dim3(256), 0, st, ra);
 }
 
 #ifndef WGRAD_BLOCKS

@@ -585,13 +585,15 @@ extern "C" int serl_convs_prep_weights_multi(int njobs, const float* const* w, v
 // (one block per CU), so nothing of the other streams runs next to it: -1 % on the whole update, hence not the default.
 // 4 = as 1 with the one-set fused layers-1+2 kernel (pconv_fused12_kernel) instead of the two-set one.
 // 5 = as 1 without the fused conv2-data-gradient + conv1-weight-gradient kernel (serl_convs_dgrad_wgrad1_supported says 0).
-static int g_patch_kernels = 1, g_ring_kernels = 0, g_wide_kernels = 1, g_f12_two_sets = 1, g_dgw1 = 1;
+// 6 = as 1 without the layer-1-keeping variant of the fused forward (serl_convs_fwd12_keep_supported says 0).
+static int g_patch_kernels = 1, g_ring_kernels = 0, g_wide_kernels = 1, g_f12_two_sets = 1, g_dgw1 = 1, g_f12_keep = 1;
 extern "C" int serl_convs_set_patch_kernels(int enable) {
   g_patch_kernels = enable ? 1 : 0;
   g_ring_kernels = enable == 3 ? 1 : 0;
   g_wide_kernels = enable == 1 || enable == 3 || enable == 4 ? 1 : 0;
   g_f12_two_sets = enable == 4 ? 0 : 1;
   g_dgw1 = enable == 5 ? 0 : 1;
+  g_f12_keep = enable == 6 ? 0 : 1;
   return SERL_OK;
 }
 
@@ -678,31 +680,59 @@ static bool fused12_fits(int IH1, int IW1, int C1, int F1, int F2) {
 extern "C" int serl_convs_fwd12_supported(int IH1, int IW1, int C1, int F1, int F2) {
   return fused12_fits(IH1, IW1, C1, F1, F2) ? 1 : 0;
 }
-extern "C" int serl_convs_fwd12(int ngroups, const void* const* x_u8, const void* const* wf1, const float* const* bias1,
-                                const void* const* wf2, const float* const* bias2, void* const* y, int B, int IH1,
-                                int IW1, int C1, int F1, int F2, int relu, void* const* rmask, void* stream) {
-  SERL_CHECK_ARG(ngroups >= 1 && ngroups <= MAXG, "convs_fwd12: ngroups must be in [1,%d]", MAXG);
+static int convs_fwd12_impl(const char* name, int ngroups, const void* const* x_u8, const void* const* wf1,
+                            const float* const* bias1, const void* const* wf2, const float* const* bias2, void* const* y,
+                            int B, int IH1, int IW1, int C1, int F1, int F2, int relu, void* const* rmask, void* const* y1,
+                            void* const* rmask1, void* stream) {
+  SERL_CHECK_ARG(ngroups >= 1 && ngroups <= MAXG, "%s: ngroups must be in [1,%d]", name, MAXG);
   SERL_CHECK_ARG(B > 0 && fused12_fits(IH1, IW1, C1, F1, F2),
-                 "convs_fwd12: geometry %dx%dx%d -> %d -> %d does not fit the fused kernel (serl_convs_fwd12_supported)",
+                 "%s: geometry %dx%dx%d -> %d -> %d does not fit the fused kernel (serl_convs_fwd12_supported)", name,
                  IH1, IW1, C1, F1, F2);
-  SERL_CHECK_ARG((long long)B * IH1 * IW1 * C1 < (1ll << 31), "convs_fwd12: tensor exceeds 2^31 elements");
+  SERL_CHECK_ARG((long long)B * IH1 * IW1 * C1 < (1ll << 31), "%s: tensor exceeds 2^31 elements", name);
   SERL_CHECK_ARG(all_aligned16(x_u8, ngroups) && all_aligned16(wf1, ngroups) && all_aligned16(wf2, ngroups) &&
-                 all_aligned16(y, ngroups), "convs_fwd12: frames, weights and output must be 16-byte aligned");
+                 all_aligned16(y, ngroups), "%s: frames, weights and output must be 16-byte aligned", name);
+  if (y1 != nullptr) {
+    bool ok = g_f12_two_sets != 0;
+    for (int i = 0; i < ngroups; ++i) ok = ok && (((uintptr_t)y1[i]) & 15) == 0;     // NULL: that group keeps nothing
+    SERL_CHECK_ARG(ok, "%s: keeping layer 1's output needs the two-set kernel (serl_convs_fwd12_keep_supported) and 16-byte aligned buffers", name);
+  }
   PConvFusedArgs a;
   a.B = B; a.IH1 = IH1; a.IW1 = IW1; a.C1 = C1; a.relu = relu;
-  const int IH = (IH1 - 3) / 2 + 1;
+  a.IH = (IH1 - 3) / 2 + 1;
   a.IW = (IW1 - 3) / 2 + 1;
-  a.OH = (IH - 3) / 2 + 1; a.OW = (a.IW - 3) / 2 + 1;
+  a.OH = (a.IH - 3) / 2 + 1; a.OW = (a.IW - 3) / 2 + 1;
   a.nbands = cdiv(a.OH, g_f12_two_sets ? PFusedPPCfg::R : PFusedCfg::R);
   a.d_bands = make_fastdiv(a.nbands);
   for (int i = 0; i < ngroups; ++i) {
-    SERL_CHECK_ARG(bias1[i] && bias2[i], "convs_fwd12: null bias");
+    SERL_CHECK_ARG(bias1[i] && bias2[i], "%s: null bias", name);
     a.u8[i] = (const unsigned char*)x_u8[i]; a.wf1[i] = (const ushort_t*)wf1[i]; a.bias1[i] = bias1[i];
     a.wf2[i] = (const ushort_t*)wf2[i]; a.bias2[i] = bias2[i]; a.y[i] = (ushort_t*)y[i];
     a.rmask[i] = rmask ? (unsigned char*)rmask[i] : nullptr;
+    a.y1[i] = y1 ? (ushort_t*)y1[i] : nullptr;
+    a.rmask1[i] = rmask1 ? (unsigned char*)rmask1[i] : nullptr;
+    SERL_CHECK_ARG(a.y1[i] != nullptr || a.rmask1[i] == nullptr, "%s: a layer-1 mask needs the layer-1 output buffer of that group", name);
   }
   if (g_f12_two_sets) return pconv_fused12pp_launch(a, ngroups, (hipStream_t)stream, "convs_fwd12(two sets)");
   return pconv_fused12_launch(a, ngroups, (hipStream_t)stream, "convs_fwd12");
+}
+extern "C" int serl_convs_fwd12(int ngroups, const void* const* x_u8, const void* const* wf1, const float* const* bias1,
+                                const void* const* wf2, const float* const* bias2, void* const* y, int B, int IH1,
+                                int IW1, int C1, int F1, int F2, int relu, void* const* rmask, void* stream) {
+  return convs_fwd12_impl("convs_fwd12", ngroups, x_u8, wf1, bias1, wf2, bias2, y, B, IH1, IW1, C1, F1, F2, relu, rmask,
+                          nullptr, nullptr, stream);
+}
+// serl_convs_fwd12 for a pass whose backward follows: the groups with y1[i] != NULL also get layer 1's output (S format
+// [B][IH][IW][32], what serl_convs_fwd(in_u8 = 1) stores -- rows 0 .. 2 OH, the ones layer 2 reads) and, with rmask1[i], its
+// ReLU byte mask, written from the kernel's LDS patch: layer 1's output is written once and not read back by layer 2.
+extern "C" int serl_convs_fwd12_keep_supported(int IH1, int IW1, int C1, int F1, int F2) {
+  return g_patch_kernels && g_f12_two_sets && g_f12_keep && fused12_fits(IH1, IW1, C1, F1, F2) ? 1 : 0;
+}
+extern "C" int serl_convs_fwd12_keep(int ngroups, const void* const* x_u8, const void* const* wf1,
+                                     const float* const* bias1, const void* const* wf2, const float* const* bias2,
+                                     void* const* y, int B, int IH1, int IW1, int C1, int F1, int F2, int relu,
+                                     void* const* rmask, void* const* y1, void* const* rmask1, void* stream) {
+  return convs_fwd12_impl("convs_fwd12_keep", ngroups, x_u8, wf1, bias1, wf2, bias2, y, B, IH1, IW1, C1, F1, F2, relu,
+                          rmask, y1, rmask1, stream);
 }
 
 extern "C" int serl_convs_dgrad(int ngroups, const void* const* dz, const void* const* wd, const void* const* xact,

@@ -271,6 +271,7 @@ struct serl_learner {
   bool ens_fused = getenv("SERL_AMD_ENS_FUSED") == nullptr || strcmp(getenv("SERL_AMD_ENS_FUSED"), "0") != 0;   // A/B switch
   bool pol_fused = getenv("SERL_AMD_POL_FUSED") == nullptr || strcmp(getenv("SERL_AMD_POL_FUSED"), "0") != 0;   // A/B switch
   bool ens_bwd_fused = getenv("SERL_AMD_ENS_BWD_FUSED") == nullptr || strcmp(getenv("SERL_AMD_ENS_BWD_FUSED"), "0") != 0;   // A/B switch
+  bool f12_keep = getenv("SERL_AMD_CONV_F12_KEEP") == nullptr || strcmp(getenv("SERL_AMD_CONV_F12_KEEP"), "0") != 0;   // A/B switch
   bool fuse_dgw1 = getenv("SERL_AMD_CONV_DGW1") == nullptr || strcmp(getenv("SERL_AMD_CONV_DGW1"), "0") != 0;   // A/B switch
   bool fuse12 = getenv("SERL_AMD_CONV_FUSE12") == nullptr || strcmp(getenv("SERL_AMD_CONV_FUSE12"), "0") != 0;   // A/B switch
   std::vector<TimeRec> trecs;
@@ -336,6 +337,12 @@ void conv_cost(int kind, int in_u8, int n, int B, const ConvL& L, double* flops,
   const double y = (double)n * B * L.OH * L.OW * L.F * 4;
   const double w = (double)n * L.K * L.K * L.C * L.F * 4;
   *flops = 2.0 * n * B * L.OH * L.OW * L.F * L.K * L.K * L.C;
+  if (kind == 5) {   // kind 3 with layer 1's output + byte masks kept for half of the groups (the critic pass next to the target pass)
+    conv_cost(3, in_u8, n, B, L, flops, bytes);
+    const int oh2 = (L.OH - 3) / 2 + 1, ow2 = (L.OW - 3) / 2 + 1;
+    *bytes += 0.5 * n * ((double)B * L.OH * L.OW * L.F * (4 + 0.125) + (double)B * oh2 * ow2 * 64 * 0.125);
+    return;
+  }
   if (kind == 3) {   // layers 1 + 2 fused (L = layer 1, layer 2 = 3x3 stride 2 -> 64): frames in, layer-2 output out
     const int oh2 = (L.OH - 3) / 2 + 1, ow2 = (L.OW - 3) / 2 + 1, f2 = 64;
     *flops += 2.0 * n * B * oh2 * ow2 * f2 * 9.0 * L.F;
@@ -445,8 +452,10 @@ int encoder_fwd(serl_learner* h, const Pass* passes, int npass, int B, Workspace
     {
       const bool fits = split && h->fuse12 && nl >= 2 && c.L[0].K == 3 && c.L[0].S == 2 && c.L[1].K == 3 && c.L[1].S == 2 &&
                         serl_convs_fwd12_supported(c.L[0].IH, c.L[0].IW, c.L[0].C, c.L[0].F, c.L[1].F);
+      // ... unless the fused kernel can keep layer 1's output for it (serl_convs_fwd12_keep): then every pass is fused
+      const bool keep = fits && h->f12_keep && serl_convs_fwd12_keep_supported(c.L[0].IH, c.L[0].IW, c.L[0].C, c.L[0].F, c.L[1].F);
       for (int i = 0; i < n; ++i) {
-        fused[i] = fits && !(mask_tag && ch[i].p->tag == mask_tag);
+        fused[i] = fits && (keep || !(mask_tag && ch[i].p->tag == mask_tag));
         nfused += fused[i];
       }
     }
@@ -489,8 +498,8 @@ int encoder_fwd(serl_learner* h, const Pass* passes, int npass, int B, Workspace
       if (li == 0 && nfused > 0) {
         const ConvL& L1 = c.L[1];
         const void* fx[MAXG_]; const void* f1[MAXG_]; const void* f2[MAXG_]; const float* fb1[MAXG_]; const float* fb2[MAXG_];
-        void* fy[MAXG_];
-        int fi[MAXG_], k = 0;
+        void* fy[MAXG_]; void* fy1[MAXG_]; void* frm1[MAXG_]; void* frm2[MAXG_];
+        int fi[MAXG_], k = 0, nkeep = 0;
         for (int i = 0; i < n; ++i) {
           if (!fused[i]) continue;
           const Pass* p = ch[i].p;
@@ -498,11 +507,23 @@ int encoder_fwd(serl_learner* h, const Pass* passes, int npass, int B, Workspace
           fb1[k] = p->store.at(p->eo->cb[ch[i].ci][0]); fb2[k] = p->store.at(p->eo->cb[ch[i].ci][1]);
           WSF(ws, st, y, (size_t)B * L1.OH * L1.OW * L1.F, "act1_%c_%d", p->tag, ch[i].ci);
           fy[k] = y; fi[k] = i;
+          fy1[k] = nullptr; frm1[k] = nullptr; frm2[k] = nullptr;
+          if (mask_tag && p->tag == mask_tag) {      // the pass with a backward: layer 1's output and both ReLU masks
+            WSF(ws, st, y0, (size_t)B * L.OH * L.OW * L.F, "act0_%c_%d", p->tag, ch[i].ci);
+            WSF(ws, st, r0, rmask_floats(B, L), "rmask0_%c_%d", p->tag, ch[i].ci);
+            fy1[k] = y0; frm1[k] = r0;
+            if (nl > 2) {
+              WSF(ws, st, r1, rmask_floats(B, L1), "rmask1_%c_%d", p->tag, ch[i].ci);
+              frm2[k] = r1;
+            }
+            ++nkeep;
+          }
           ++k;
         }
         Timed t{h, st};
-        DRV(t.begin(3, 1, k, B, L));
-        DRV(serl_convs_fwd12(k, fx, f1, fb1, f2, fb2, fy, B, L.IH, L.IW, L.C, L.F, L1.F, 1, nullptr, st));
+        DRV(t.begin(nkeep ? 5 : 3, 1, k, B, L));
+        if (nkeep) DRV(serl_convs_fwd12_keep(k, fx, f1, fb1, f2, fb2, fy, B, L.IH, L.IW, L.C, L.F, L1.F, 1, frm2, fy1, frm1, st));
+        else DRV(serl_convs_fwd12(k, fx, f1, fb1, f2, fb2, fy, B, L.IH, L.IW, L.C, L.F, L1.F, 1, nullptr, st));
         DRV(t.end());
         for (int q = 0; q < k; ++q) xs[fi[q]] = fy[q];
       }
@@ -1921,7 +1942,7 @@ extern "C" int serl_learner_set_timing(serl_learner* h, int conv_events, int pha
   return SERL_OK;
 }
 extern "C" int serl_learner_timing_count(serl_learner* h) { return h ? (int)h->trecs.size() : 0; }
-// record i -> desc[7] = {kind (0 fwd, 1 dgrad, 2 wgrad, 3 fused layers 1+2 fwd, 4 conv2 dgrad + conv1 wgrad), in_u8, groups, B, IH, C, F}, val[3] = {ms, flops, bytes};
+// record i -> desc[7] = {kind (0 fwd, 1 dgrad, 2 wgrad, 3 fused layers 1+2 fwd, 4 conv2 dgrad + conv1 wgrad, 5 fused layers 1+2 fwd keeping layer 1 for half the groups), in_u8, groups, B, IH, C, F}, val[3] = {ms, flops, bytes};
 // call after a device synchronise.
 extern "C" int serl_learner_timing_get(serl_learner* h, int i, int* desc, double* val) {
   SERL_CHECK_ARG(h && desc && val && i >= 0 && i < (int)h->trecs.size(), "learner_timing_get: bad index");

@@ -1137,7 +1137,11 @@ struct PConvFusedArgs {
   const float* bias2[MAXG];
   unsigned short* y[MAXG];            // layer-2 output, S format [B][OH][OW][64]
   unsigned char* rmask[MAXG];
-  int B, IH1, IW1, C1, IW, OH, OW, nbands, relu;     // IW: layer-1 output width = layer-2 input width
+  // the pass whose backward follows also keeps layer 1's output (S format [B][IH][IW][32]) and its ReLU byte mask
+  // ([B*IH*IW][4]): written from the LDS patch by the two-set kernel, nullptr for the no-gradient passes
+  unsigned short* y1[MAXG];
+  unsigned char* rmask1[MAXG];
+  int B, IH1, IW1, C1, IH, IW, OH, OW, nbands, relu;     // IH, IW: layer-1 output = layer-2 input
   FastDiv d_bands;
 };
 
@@ -1524,6 +1528,8 @@ __global__ __launch_bounds__(512, 1) void pconv_fused12pp_kernel(const PConvFuse
   for (int j = 0; j < 8; ++j) bs[j] = a.bias2[z][n8 + j];
   unsigned short* const out = a.y[z];
   unsigned char* const mk = a.rmask[z];
+  unsigned short* const y1g = a.y1[z];
+  unsigned char* const mk1 = a.rmask1[z];
 
   // uint8 rows 4*oy0 .. 4*oy0 + 4*rows + 2 of image b -> this set's buffer: 3 pieces per lane + a 13th KB that all four
   // waves copy (the same bytes to the same place)
@@ -1760,6 +1766,42 @@ __global__ __launch_bounds__(512, 1) void pconv_fused12pp_kernel(const PConvFuse
       if (mk != nullptr) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
       PF_TP(4)
+      // ---- the pass with a backward keeps layer 1's output: this item's patch rows go to memory as they are (the S-format
+      // records of serl_convs_fwd(in_u8 = 1), unswizzled) with their ReLU byte mask.  A band owns its first 2 rows' worth
+      // (the last row is the next band's first), the last band of an image its last row too.  Issued behind the counted
+      // wait above: the stores stay in flight into the next slots (older than this set's next DMA).  Row y by wave y & 3;
+      // 8 lanes per record (128 bytes contiguous), 16-lane groups read records j, j + 1 of one parity: distinct banks.
+      if (y1g != nullptr) {
+        const int nsave = 2 * min(R, a.OH - oy0) + (band == a.nbands - 1 ? 1 : 0);
+        for (int y = w4; y < nsave; y += 4) {
+          const size_t rowpix = ((size_t)b * a.IH + 2 * oy0 + y) * a.IW;
+          u32x4_t v[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int par = i & 1, j = (i >> 1) * 8 + (lane >> 3), c = lane & 7;
+            const uint32_t la = patch_l + (uint32_t)(y * ROWB + par * PARB + j * REC + ((c ^ pconv_swz<REC>(j)) << 4));
+            asm volatile("ds_read_b128 %0, %1" : "=v"(v[i]) : "v"(la) : "memory");
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) : : "memory");
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int par = i & 1, j = (i >> 1) * 8 + (lane >> 3), c = lane & 7;
+            const int ix = 2 * j + par;
+            if (ix < a.IW) {
+              *reinterpret_cast<u32x4_t*>(y1g + (rowpix + ix) * 2 * C + c * 8) = v[i];
+              if (mk1 != nullptr && c < 4) {
+                uint32_t bits = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  bits |= (v[i][e] & 0x7fffu) ? (1u << (2 * e)) : 0u;
+                  bits |= (v[i][e] & 0x7fff0000u) ? (2u << (2 * e)) : 0u;
+                }
+                mk1[(rowpix + ix) * (C >> 3) + c] = (unsigned char)bits;
+              }
+            }
+          }
+        }
+      }
     }
     __builtin_amdgcn_s_barrier();
     PF_TP(5)

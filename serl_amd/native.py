@@ -209,7 +209,7 @@ class NativeLearner:
     def conv_timings(self):
         """[(kind, in_u8, groups, B, IH, C, F), ms, flops, bytes] of every conv launch since the last reset (after a sync)."""
         lib = _lib.load()
-        kinds = ("convs_fwd", "convs_dgrad", "convs_wgrad", "convs_fwd12", "convs_dgw1")
+        kinds = ("convs_fwd", "convs_dgrad", "convs_wgrad", "convs_fwd12", "convs_dgw1", "convs_fwd12keep")
         out = []
         desc, val = (C.c_int * 7)(), (C.c_double * 3)()
         for i in range(lib.serl_learner_timing_count(self._h)):

@@ -105,6 +105,22 @@ def convs_fwd12(xs, wf1s, b1s, wf2s, b2s, ys, B, IH1, IW1, C1, F1, F2, relu, str
     call("serl_convs_fwd12", n, px, p1, pb1, p2, pb2, py, B, IH1, IW1, C1, F1, F2, int(relu), pm, stream)
 
 
+def convs_fwd12_keep(xs, wf1s, b1s, wf2s, b2s, ys, B, IH1, IW1, C1, F1, F2, relu, stream, rmasks=None, y1s=None, rmask1s=None):
+    """convs_fwd12 that also writes layer 1's output (and its ReLU byte mask) for the groups with a y1 pointer."""
+    n = len(xs)
+    px, kx = ptr_table(xs); p1, k1 = ptr_table(wf1s); pb1, kb1 = ptr_table(b1s); p2, k2 = ptr_table(wf2s)
+    pb2, kb2 = ptr_table(b2s); py, ky = ptr_table(ys)
+    pm, km = ptr_table(rmasks) if rmasks is not None else (None, None)
+    py1, ky1 = ptr_table(y1s) if y1s is not None else (None, None)
+    pm1, km1 = ptr_table(rmask1s) if rmask1s is not None else (None, None)
+    call("serl_convs_fwd12_keep", n, px, p1, pb1, p2, pb2, py, B, IH1, IW1, C1, F1, F2, int(relu), pm, py1, pm1, stream)
+
+
+def convs_fwd12_keep_supported(IH1, IW1, C1, F1, F2):
+    from ._lib import load
+    return bool(load().serl_convs_fwd12_keep_supported(IH1, IW1, C1, F1, F2))
+
+
 def convs_fwd12_supported(IH1, IW1, C1, F1, F2):
     from ._lib import load
     return bool(load().serl_convs_fwd12_supported(IH1, IW1, C1, F1, F2))

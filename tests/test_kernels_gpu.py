@@ -422,6 +422,33 @@ def _fwd12_case(ops, dev, case):
     assert bool((mb[1] == 0x55).all()), "a NULL mask entry must not be written"
     got = _from_s(ops, yb[0], B * OH * OW, F2, st)
     assert np.isfinite(got).all() and (got > 0).mean() > 0.05          # not trivially dead
+    # ---- the variant that keeps layer 1's output for the backward (two-set kernel): groups 0 and 2 get it, group 0 its
+    # ReLU byte mask too; same bits as serl_convs_fwd(in_u8 = 1) on the rows layer 2 reads, nothing else touched
+    if not ops.convs_fwd12_keep_supported(IH1, IW1, C1, F1, F2):
+        return
+    m1ref = torch.full((B * IH * IW * F1 // 8,), 0xAA, dtype=torch.uint8, device=dev)
+    y1r = [torch.full_like(t, -1) for t in y1]
+    ops.convs_fwd(p(xs), p(wf1), p(b1), p(y1r), True, B, IH1, IW1, C1, K, K, S, F1, True, st, rmasks=[m1ref.data_ptr(), 0, 0])
+    yc = [torch.full_like(t, -2) for t in ya]
+    mc = [torch.full_like(t, 0x55) for t in ma]
+    y1k = [torch.full_like(t, -3) for t in y1]
+    m1k = torch.full_like(m1ref, 0x33)
+    ops.convs_fwd12_keep(p(xs), p(wf1), p(b1), p(wf2), p(b2), p(yc), B, IH1, IW1, C1, F1, F2, True, st,
+                         rmasks=[mc[0].data_ptr(), 0, mc[2].data_ptr()], y1s=[y1k[0].data_ptr(), 0, y1k[2].data_ptr()],
+                         rmask1s=[m1k.data_ptr(), 0, 0])
+    torch.cuda.synchronize()
+    for g in range(G):
+        assert torch.equal(ya[g], yc[g]), f"keep variant: layer-2 output differs, group {g}"
+    assert torch.equal(ma[0], mc[0]) and torch.equal(ma[2], mc[2])
+    nr = 2 * OH + 1                                                     # layer-1 rows that layer 2 reads
+    for g in (0, 2):
+        a_, b_ = y1r[g].view(B, IH, -1), y1k[g].view(B, IH, -1)
+        assert torch.equal(a_[:, :nr], b_[:, :nr]), f"kept layer-1 output differs, group {g}"
+        assert bool((b_[:, nr:] == -3).all()), "rows layer 2 does not read must stay untouched"
+    assert bool((y1k[1] == -3).all()), "a NULL layer-1 entry must not be written"
+    a_, b_ = m1ref.view(B, IH, -1), m1k.view(B, IH, -1)
+    assert torch.equal(a_[:, :nr], b_[:, :nr]), "kept layer-1 ReLU byte mask differs"
+    assert bool((b_[:, nr:] == 0x33).all())
 
 
 # ---------------------------------------------------------------------------------- igemm: dense
