@@ -431,7 +431,9 @@ def main():
         summ = {k: (v[0], v[1] / v[0], v[2], v[3]) for k, v in summ.items()}
         fams = {}
         for k, (n_, ms_, fl_, by_) in summ.items():
-            f = fams.setdefault(k[:2] + k[3:], dict(n=0, t=0.0, fl=0.0, by=0.0, tr=0.0, tr_ok=True, src=None, groups=[]))
+            # (the fused layers-1+2 kernel is one instantiation whether or not some groups keep layer 1's output)
+            f = fams.setdefault((k[0].replace("fwd12keep", "fwd12"),) + k[1:2] + k[3:],
+                                dict(n=0, t=0.0, fl=0.0, by=0.0, tr=0.0, tr_ok=True, src=None, groups=[]))
             tr, src = measured_traffic(k)
             f["n"] += n_; f["t"] += n_ * ms_; f["fl"] += n_ * fl_; f["by"] += n_ * by_
             f["tr_ok"] = f["tr_ok"] and tr is not None

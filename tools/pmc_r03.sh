@@ -9,7 +9,7 @@ P1="SQ_WAVES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS 
 P2="SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VMEM SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM_RD"
 P3="TCP_PENDING_STALL_CYCLES_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum SQ_ACTIVE_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE"
 D=gpurun_out/pmc_r03
-CMD="mkdir -p $D && cd /tmp && export TMPDIR=/tmp && export BENCH_N=2 BENCH_ONLY='conv2 fwd,conv2 dgrad,conv2 wgrad,conv3 fwd,conv3 dgrad,conv3 wgrad,conv4 fwd,conv4 dgrad,conv4 wgrad,conv1 wgrad'"
+CMD="mkdir -p $D && cd /tmp && export TMPDIR=/tmp && export BENCH_N=2 BENCH_ONLY='conv2 fwd,conv2 dgrad,conv2 wgrad,conv3 fwd,conv3 dgrad,conv3 wgrad,conv4 fwd,conv4 dgrad,conv4 wgrad,conv1 wgrad,dgw1'"
 i=0
 for P in "$P1" "$P2" "$P3"; do
   i=$((i+1))
@@ -27,6 +27,7 @@ NAMES = [("pconv_fused12pp_kernel", "layers 1+2 fused, no-gradient passes (pconv
          ("pconv_fwd_kernel", "conv2 forward patch kernel (pconv_fwd_kernel), 4 groups"),
          ("pconv_dgrad_kernel", "conv2 data gradient patch kernel (pconv_dgrad_kernel), 2 groups"),
          ("pconv_wgrad_kernel", "conv2 weight gradient patch kernel (pconv_wgrad_kernel), 2 groups"),
+         ("pconv_dgw1_kernel", "conv2 data gradient + conv1 weight gradient in one kernel (pconv_dgw1_kernel), 2 groups"),
          ("pconv_fwdw_kernel", "conv3 forward wide patch kernel (pconv_fwdw_kernel), 4 groups"),
          ("pconv_dgradw_kernel", "conv3 data gradient wide patch kernel (pconv_dgradw_kernel), 2 groups"),
          ("sgemm_kernel<ConvFwdS<false>", "conv4 forward, register-staged im2col (sgemm_kernel<ConvFwdS>), 4 groups"),
