@@ -585,8 +585,9 @@ extern "C" int serl_convs_prep_weights_multi(int njobs, const float* const* w, v
 // (one block per CU), so nothing of the other streams runs next to it: -1 % on the whole update, hence not the default.
 // 4 = as 1 with the one-set fused layers-1+2 kernel (pconv_fused12_kernel) instead of the two-set one.
 // 5 = as 1 without the fused conv2-data-gradient + conv1-weight-gradient kernel (serl_convs_dgrad_wgrad1_supported says 0).
+// 7 = as 1 with conv3's weight gradient on the im2col kernel.
 // 6 = as 1 without the layer-1-keeping variant of the fused forward (serl_convs_fwd12_keep_supported says 0).
-static int g_patch_kernels = 1, g_ring_kernels = 0, g_wide_kernels = 1, g_f12_two_sets = 1, g_dgw1 = 1, g_f12_keep = 1;
+static int g_patch_kernels = 1, g_ring_kernels = 0, g_wide_kernels = 1, g_f12_two_sets = 1, g_dgw1 = 1, g_f12_keep = 1, g_wgradw = 1;
 extern "C" int serl_convs_set_patch_kernels(int enable) {
   g_patch_kernels = enable ? 1 : 0;
   g_ring_kernels = enable == 3 ? 1 : 0;
@@ -594,6 +595,7 @@ extern "C" int serl_convs_set_patch_kernels(int enable) {
   g_f12_two_sets = enable == 4 ? 0 : 1;
   g_dgw1 = enable == 5 ? 0 : 1;
   g_f12_keep = enable == 6 ? 0 : 1;
+  g_wgradw = enable == 7 ? 0 : 1;
   return SERL_OK;
 }
 
@@ -859,6 +861,24 @@ static int convs_wgrad_impl(const char* name, int ngroups, const void* const* x,
     for (int i = 0; i < ngroups; ++i) { a.x[i] = (const ushort_t*)x[i]; a.dz[i] = (const ushort_t*)dz[i]; }
     int nslab = 0;
     if (int e = pconv_wgrad_launch(a, ngroups, nsplit, workspace_bytes, &nslab, (hipStream_t)stream, name)) return e;
+    if (nslab > 0) {
+      ReduceArgs ra; ra.slab = workspace; ra.nsplit = nslab; ra.kkc = kkc; ra.F = F;
+      for (int i = 0; i < ngroups; ++i) { ra.dw[i] = dw[i]; ra.db[i] = dbias[i]; }
+      launch_wgrad_reduce(ra, ngroups, (hipStream_t)stream);
+      SERL_CHECK_LAUNCH("wgrad_reduce");
+      return SERL_OK;
+    }
+  }
+  if (g_patch_kernels && g_wide_kernels && g_wgradw && !in_u8 && KH == 3 && KW == 3 && stride == 2 && C == 64 && F == 128 &&
+      g.OW <= 15 && (IW + 1) / 2 <= 16 && workspace != nullptr) {
+    // the same scheme for the third layer (pconv_wgradw_kernel): 76 accumulator tiles persistent in an 8-wave block
+    PConvWgradArgs a;
+    a.B = B; a.IH = IH; a.IW = IW; a.OH = g.OH; a.OW = g.OW; a.slab = workspace;
+    a.nbands = cdiv(g.OH, PWgradWCfg::R);
+    a.d_bands = make_fastdiv(a.nbands);
+    for (int i = 0; i < ngroups; ++i) { a.x[i] = (const ushort_t*)x[i]; a.dz[i] = (const ushort_t*)dz[i]; }
+    int nslab = 0;
+    if (int e = pconv_wgradw_launch(a, ngroups, nsplit, workspace_bytes, &nslab, (hipStream_t)stream, name)) return e;
     if (nslab > 0) {
       ReduceArgs ra; ra.slab = workspace; ra.nsplit = nslab; ra.kkc = kkc; ra.F = F;
       for (int i = 0; i < ngroups; ++i) { ra.dw[i] = dw[i]; ra.db[i] = dbias[i]; }

@@ -2036,3 +2036,265 @@ static int pconv_wgrad_launch(PConvWgradArgs& a, int ngroups, int max_slabs, lon
   SERL_CHECK_LAUNCH(name);
   return SERL_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ weight gradient, wide layer
+// The same weight gradient for C = 64, F = 128 (third layer of the encoder: x 31 x 31 x 64, dz 15 x 15 x 128).  The im2col
+// kernel needs 103 split-K slabs per camera to fill the chip (61 MB written and read back per step, and the reduction
+// behind it takes as long as the GEMM inside the update).  Here the 9 taps x 2 channel halves + the all-ones row are 19 M
+// tiles, F is 4 N tiles: 76 accumulator tiles = 5 x 2 per wave of an 8-wave block (160 registers), persistent over all items
+// of the block, which writes ONE slab.  An item is a band of R = 2 output rows of one image: 5 rows of x (256-byte records,
+// [row][parity][j], 16 per parity) and 2 rows of dz (512-byte records, 16 per row: record 15 is zero) by LDS-DMA, x three
+// and dz two buffers deep; one k16 step per output row, both operands by ds_read_b64_tr_b16 as in pconv_wgrad_kernel.
+struct PWgradWCfg {
+  static constexpr int C = 64, F = 128, R = 2, NW = 8, NT = 64 * NW;
+  static constexpr int XREC = 4 * C, XPARB = 16 * XREC, XROWB = 2 * XPARB, XROWS = 2 * R + 1;
+  static constexpr int XPATCH = XROWS * XROWB;              // 40 KB
+  static constexpr int ZREC = 4 * F, ZROWB = 16 * ZREC;
+  static constexpr int ZPATCH = R * ZROWB;                  // 16 KB
+  // x bands three deep, dz bands two deep: per item the block computes for ~1 us, an LDS-DMA burst of a band takes 2-3 us to
+  // land, so two x bands (the larger operand) are in flight while a third is multiplied
+  static constexpr int NXB = 3, NZB = 2, OFF_Z = NXB * XPATCH, OFF_ONES = OFF_Z + NZB * ZPATCH;
+  static constexpr int ONES = 512;                          // a constant x record: channel 0 = 1.0 (the bias gradient's A operand), then zeros
+  static constexpr int LDS = OFF_ONES + ONES;
+  static constexpr int XPIECES = XPATCH / 16 / NT, ZPIECES = ZPATCH / 16 / NT;   // 5, 2
+  static constexpr int MTILES = 9 * (C / 32) + 1, MPW = 5;  // 19 M tiles, 5 per wave group (the last group: 4)
+  static constexpr int SLAB = (9 * C + 1) * F;              // floats per slab
+  static_assert(XPATCH % (16 * NT) == 0 && ZPATCH % (16 * NT) == 0 && LDS <= 160 * 1024 && 4 * MPW >= MTILES, "shape");
+};
+
+// four transposing LDS reads from two lane addresses with immediate offsets (issued, not waited for)
+#define PCONV_TR4I(o0, o1, o2, o3, a0, a1, a2, a3, imm)                                                                \
+  asm volatile("ds_read_b64_tr_b16 %0, %4 offset:%8\n\tds_read_b64_tr_b16 %1, %5 offset:%8\n\t"                          \
+               "ds_read_b64_tr_b16 %2, %6 offset:%8\n\tds_read_b64_tr_b16 %3, %7 offset:%8"                              \
+               : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3)                                                             \
+               : "v"((uint32_t)(a0)), "v"((uint32_t)(a1)), "v"((uint32_t)(a2)), "v"((uint32_t)(a3)), "n"(imm)           \
+               : "memory")
+
+// the item loop of wave group MG (M tiles 5 MG .. 5 MG + 4, compile-time: every tile's row / parity offset is an immediate)
+template <int MG>
+__device__ __forceinline__ void pwgradw_items(const PConvWgradArgs& a, unsigned char* p_smem, int z, int it0, int it1, int tid,
+                                              int wid, f32x16 (&acc)[PWgradWCfg::MPW][2]) {
+  typedef PWgradWCfg G;
+  constexpr int R = G::R, NW = G::NW, MPW = G::MPW;
+  constexpr int MT0 = MG * MPW, NTILE = MT0 + MPW <= G::MTILES ? MPW : G::MTILES - MT0;   // tiles of this group (5, 5, 5, 4)
+  typedef short s16x8_t __attribute__((ext_vector_type(8)));
+  const int lane = tid & 63, h = lane >> 5, np = wid & 1;
+  const int tr_q = (lane & 15) >> 2, tr_p = lane & 3, tr_cb = lane & 16;
+  const uint32_t smem_base = (uint32_t)(size_t)(pconv_lptr_t)p_smem;
+
+  // live == false (past the block's last item): the same number of DMA instructions, all from the zero page
+  auto dma_x = [&](int item, bool live, unsigned char* buf) {
+    const int b = (int)fd_div((uint32_t)item, a.d_bands), band = item - b * a.nbands;
+    const int oy0 = band * R;
+    const char* xsrc = reinterpret_cast<const char*>(a.x[z]) + ((size_t)(b * a.IH + 2 * oy0) * a.IW) * G::XREC;
+    const int xrows = live ? min(G::XROWS, a.IH - 2 * oy0) : 0;
+    int ln = tid & 63;
+    asm volatile("" : "+v"(ln));            // per-lane address terms recomputed per item, not kept in (spilled) registers
+#pragma unroll
+    for (int i = 0; i < G::XPIECES; ++i) {
+      const int l = (i * NW + wid) * 64 + ln;
+      const int rec = l >> 4, chp = l & 15;
+      const int rr = rec >> 5, par = (rec >> 4) & 1, j = rec & 15;
+      const int ix = 2 * j + par;
+      const bool ok = rr < xrows && ix < a.IW;
+      const char* g = ok ? xsrc + (size_t)(((rr * a.IW + ix) << 4) + (chp ^ pconv_swz<G::XREC>(j))) * 16
+                         : reinterpret_cast<const char*>(g_zero_page);
+      __builtin_amdgcn_global_load_lds((pconv_gptr_t)g, (pconv_lptr_t)(buf + (i * NW + wid) * 1024), 16, 0, 0);
+    }
+  };
+  auto dma_z = [&](int item, bool live, unsigned char* buf) {
+    const int b = (int)fd_div((uint32_t)item, a.d_bands), band = item - b * a.nbands;
+    const int oy0 = band * R;
+    const char* zsrc = reinterpret_cast<const char*>(a.dz[z]) + ((size_t)(b * a.OH + oy0) * a.OW) * G::ZREC;
+    const int zrows = live ? a.OH - oy0 : 0;
+    int ln = tid & 63;
+    asm volatile("" : "+v"(ln));
+#pragma unroll
+    for (int i = 0; i < G::ZPIECES; ++i) {
+      const int l = (i * NW + wid) * 64 + ln;
+      const int rec = l >> 5, chp = l & 31;
+      const int row = rec >> 4, ox = rec & 15;
+      const bool ok = row < zrows && ox < a.OW;
+      const char* g = ok ? zsrc + (size_t)(((row * a.OW + ox) << 5) + (chp ^ (ox & 15))) * 16
+                         : reinterpret_cast<const char*>(g_zero_page);
+      __builtin_amdgcn_global_load_lds((pconv_gptr_t)g, (pconv_lptr_t)(buf + (i * NW + wid) * 1024), 16, 0, 0);
+    }
+  };
+
+  // Lane addresses relative to a buffer.  This lane feeds the transposed reads with k-rows (pixels) ox0 and ox0 + 4 and 4
+  // consecutive rows (channels tr_cb + 4 tr_p .. + 3 of a 32-channel tile).  x: per (channel half, kx >> 1) the hi-plane
+  // addresses of records j0 = ox0 + (kx >> 1) and j0 + 4 in parity region 0 of row 0 (row / parity: immediates); the lo
+  // plane is 8 chunks on, i.e. address ^ 128 (the swizzle XORs the chunk bits only).  dz: per N tile the hi-plane addresses of
+  // records ox0, ox0 + 4 of row 0; lo plane = address ^ 256.
+  const int ox0 = 8 * h + tr_q;
+  const int cofs = (tr_cb + 4 * tr_p) * 2;
+  uint32_t xa[2][2][2], za[2][2];
+#pragma unroll
+  for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int co = 64 * ch + cofs, chunk = co >> 4, within = co & 15;
+        const int j = ox0 + kh + 4 * e;
+        xa[ch][kh][e] = (uint32_t)(j * G::XREC + within + ((chunk ^ pconv_swz<G::XREC>(j)) << 4));
+      }
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int co = 64 * (2 * np + t) + cofs, chunk = co >> 4, within = co & 15;
+      const int ox = ox0 + 4 * e;
+      za[t][e] = (uint32_t)(ox * G::ZREC + within + ((chunk ^ (ox & 15)) << 4));
+    }
+  const uint32_t ones_addr = smem_base + G::OFF_ONES + cofs;
+
+  // issue order per item: dz of the next item, then x of the one after it; vmcnt retires in order, so "at most the last
+  // XPIECES loads in flight" = this item's dz and x have landed, the next item's x may still be on its way
+  dma_z(it0, true, p_smem + G::OFF_Z);
+  dma_x(it0, true, p_smem);
+  dma_x(it0 + 1, it0 + 1 < it1, p_smem + G::XPATCH);
+  int xb = 0, zb = 0;
+  for (int item = it0; item < it1; ++item) {
+    const uint32_t base = smem_base + xb * G::XPATCH, zbase = smem_base + G::OFF_Z + zb * G::ZPATCH;
+    static_assert(G::XPIECES == 5, "counted wait");
+    asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();            // this item's bands landed; every wave is done with the previous item's buffers
+    const int xn = xb == 0 ? 2 : xb - 1;     // (xb + 2) % 3: the buffer of the previous item
+    dma_z(item + 1, item + 1 < it1, p_smem + G::OFF_Z + (zb ^ 1) * G::ZPATCH);
+    dma_x(item + 2, item + 2 < it1, p_smem + xn * G::XPATCH);
+#pragma unroll
+    for (int oyl = 0; oyl < R; ++oyl) {        // k16 step: output row oyl, pixels ox = 0 .. 15
+      // The fragments of M tile i + 1 are requested before the MFMAs of tile i (ring of two register sets, counted waits:
+      // LDS returns in order).
+      s16x4_t bq[2][4], aq[2][4];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const uint32_t r0 = zbase + za[t][0], r1 = zbase + za[t][1];
+        PCONV_TR4I(bq[t][0], bq[t][1], bq[t][2], bq[t][3], r0, r1, r0 ^ 256u, r1 ^ 256u, oyl * G::ZROWB);
+      }
+#define PWGW_LOAD_A(i, o)                                                                                               \
+      {                                                                                                                 \
+        constexpr int mt_ = MT0 + (i);                                                                                  \
+        if constexpr (mt_ == G::MTILES - 1) {          /* the bias tile: the constant record for every pixel */         \
+          PCONV_TR4I(o[0], o[1], o[2], o[3], ones_addr, ones_addr, ones_addr + 256u, ones_addr + 256u, 0);              \
+        } else {                                                                                                        \
+          constexpr int tap_ = mt_ >> 1, ch_ = mt_ & 1, ky_ = tap_ / 3, kx_ = tap_ - 3 * ky_;                          \
+          const uint32_t r0 = base + xa[ch_][kx_ >> 1][0], r1 = base + xa[ch_][kx_ >> 1][1];                            \
+          PCONV_TR4I(o[0], o[1], o[2], o[3], r0, r1, r0 ^ 128u, r1 ^ 128u, ((2 * oyl + ky_) * 2 + (kx_ & 1)) * G::XPARB); \
+        }                                                                                                               \
+      }
+      PWGW_LOAD_A(0, aq[0])
+      bf16x8_t bh[2], bl[2];
+#pragma unroll
+      for (int i = 0; i < NTILE; ++i) {
+        if (i + 1 < NTILE) {
+          if (i == 0) PWGW_LOAD_A(1, aq[1])
+          if (i == 1) PWGW_LOAD_A(2, aq[0])
+          if (i == 2) PWGW_LOAD_A(3, aq[1])
+          if (i == 3) PWGW_LOAD_A(4 < NTILE ? 4 : 0, aq[0])
+          asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(aq[i & 1][0]), "+v"(aq[i & 1][1]), "+v"(aq[i & 1][2]), "+v"(aq[i & 1][3]),
+                       "+v"(bq[0][0]), "+v"(bq[0][1]), "+v"(bq[0][2]), "+v"(bq[0][3]), "+v"(bq[1][0]), "+v"(bq[1][1]), "+v"(bq[1][2]), "+v"(bq[1][3]));
+        } else {
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(aq[i & 1][0]), "+v"(aq[i & 1][1]), "+v"(aq[i & 1][2]), "+v"(aq[i & 1][3]));
+        }
+        if (i == 0) {
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            bh[t] = __builtin_bit_cast(bf16x8_t, (s16x8_t){bq[t][0][0], bq[t][0][1], bq[t][0][2], bq[t][0][3], bq[t][1][0], bq[t][1][1], bq[t][1][2], bq[t][1][3]});
+            bl[t] = __builtin_bit_cast(bf16x8_t, (s16x8_t){bq[t][2][0], bq[t][2][1], bq[t][2][2], bq[t][2][3], bq[t][3][0], bq[t][3][1], bq[t][3][2], bq[t][3][3]});
+          }
+        }
+        const s16x4_t* q4 = aq[i & 1];
+        // (the bias tile: ah = the ones row, al = 0 -- the exact-zero product in front of ones x lo, ones x hi changes nothing)
+        const bf16x8_t ah = __builtin_bit_cast(bf16x8_t, (s16x8_t){q4[0][0], q4[0][1], q4[0][2], q4[0][3], q4[1][0], q4[1][1], q4[1][2], q4[1][3]});
+        const bf16x8_t al = __builtin_bit_cast(bf16x8_t, (s16x8_t){q4[2][0], q4[2][1], q4[2][2], q4[2][3], q4[3][0], q4[3][1], q4[3][2], q4[3][3]});
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[t], acc[i][t], 0, 0, 0);
+          acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[t], acc[i][t], 0, 0, 0);
+          acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[t], acc[i][t], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#undef PWGW_LOAD_A
+    }
+    xb = xb == 2 ? 0 : xb + 1;
+    zb ^= 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the (zero-page) bands requested past the last item
+}
+
+__global__ __launch_bounds__(512, 1) void pconv_wgradw_kernel(const PConvWgradArgs a) {
+  typedef PWgradWCfg G;
+  constexpr int C = G::C, F = G::F, MPW = G::MPW;
+  extern __shared__ __attribute__((aligned(16))) unsigned char p_smem[];
+  const int z = blockIdx.z;
+  const int nitems = a.B * a.nbands;
+  const int per = (nitems + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int it0 = blockIdx.x * per, it1 = min(nitems, it0 + per);    // the launcher sizes the grid so that it0 < it1
+  const int tid = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int np = wid & 1, mt0 = (wid >> 1) * MPW;             // N tiles 2 np, 2 np + 1; M tiles mt0 .. mt0 + 4 (< 19)
+  // the all-ones row of the bias gradient as data: every pixel of its "tile" reads this record, whose transposed fragment
+  // is row 0 = 1.0 for every k (hi plane), zeros elsewhere and in the lo plane
+  if (tid < G::ONES / 4) reinterpret_cast<uint32_t*>(p_smem + G::OFF_ONES)[tid] = tid == 0 ? 0x00003F80u : 0u;
+
+  f32x16 acc[MPW][2];
+#pragma unroll
+  for (int i = 0; i < MPW; ++i)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][t][q] = 0.f;
+  switch (wid >> 1) {        // one loop per wave group: tile offsets are immediates, register allocation per group
+    case 0: pwgradw_items<0>(a, p_smem, z, it0, it1, tid, wid, acc); break;
+    case 1: pwgradw_items<1>(a, p_smem, z, it0, it1, tid, wid, acc); break;
+    case 2: pwgradw_items<2>(a, p_smem, z, it0, it1, tid, wid, acc); break;
+    default: pwgradw_items<3>(a, p_smem, z, it0, it1, tid, wid, acc); break;
+  }
+  // ---- one slab per block: rows (tap, c) in HWIO order, then the bias row
+  float* slab = a.slab + ((size_t)z * gridDim.x + blockIdx.x) * G::SLAB;
+#pragma unroll
+  for (int i = 0; i < MPW; ++i) {
+    const int mt = mt0 + i;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int m = (q & 3) + 8 * (q >> 2) + 4 * (int)((threadIdx.x >> 5) & 1);
+        const int n = (2 * np + t) * 32 + (int)(threadIdx.x & 31);
+        if (mt < G::MTILES - 1) slab[(size_t)(mt * 32 + m) * F + n] = acc[i][t][q];
+        else if (mt == G::MTILES - 1 && m == 0) slab[(size_t)(9 * C) * F + n] = acc[i][t][q];
+      }
+  }
+}
+
+// as pconv_wgrad_launch: the slab count depends on the geometry and the device only
+static int pconv_wgradw_launch(PConvWgradArgs& a, int ngroups, int max_slabs, long long workspace_bytes, int* nslab,
+                               hipStream_t st, const char* name) {
+  static bool opted[64] = {};
+  static int ncu[64] = {};
+  int dev = 0;
+  SERL_CHECK_HIP(hipGetDevice(&dev), name);
+  SERL_CHECK_ARG(dev >= 0 && dev < 64, "%s: device ordinal %d out of range", name, dev);
+  if (!opted[dev]) {
+    SERL_CHECK_HIP(hipFuncSetAttribute((const void*)pconv_wgradw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PWgradWCfg::LDS), name);
+    SERL_CHECK_HIP(hipDeviceGetAttribute(&ncu[dev], hipDeviceAttributeMultiprocessorCount, dev), name);
+    opted[dev] = true;
+  }
+  const int nitems = a.B * a.nbands;
+  static int cap = -1;                    // SERL_PCONV_WGW_CUS: CUs this kernel spreads over (its slab count: a fixed choice per process)
+  if (cap < 0) { const char* e = getenv("SERL_PCONV_WGW_CUS"); cap = e ? atoi(e) : 0; }
+  const int cus = ncu[dev] > 0 ? ncu[dev] : 256;
+  int gx = (cap > 0 && cap < cus ? cap : cus) / ngroups;
+  if (gx > max_slabs) gx = max_slabs;
+  if (gx > nitems) gx = nitems;
+  if (gx < 1) { *nslab = 0; return SERL_OK; }
+  const int per = cdiv(nitems, gx);
+  gx = cdiv(nitems, per);                    // every block has at least one item
+  if ((long long)ngroups * gx * PWgradWCfg::SLAB * 4 > workspace_bytes) { *nslab = 0; return SERL_OK; }
+  *nslab = gx;
+  hipLaunchKernelGGL(pconv_wgradw_kernel, dim3(gx, 1, ngroups), dim3(PWgradWCfg::NT), PWgradWCfg::LDS, st, a);
+  SERL_CHECK_LAUNCH(name);
+  return SERL_OK;
+}
