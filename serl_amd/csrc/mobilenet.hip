@@ -13,9 +13,11 @@
 
 #include "../../include/serl_hip.h"
 #include "common.h"
+#include "igemm_bf3.h"
 
 namespace {
 
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_HSWISH = 2, ACT_HSIGMOID = 3 };
 
 __device__ __forceinline__ float act_apply(float v, int act) {
@@ -149,10 +151,124 @@ __global__ __launch_bounds__(256) void se_scale_kernel(float* x, const float* ga
   ((float4*)x)[idx] = v;
 }
 
+// ---- streaming pointwise convolution for the wide, shallow layers of the first blocks (M = n H W rows of 16..72 channels
+// in, 16..72 out: 25..335 MB of activations against a few KB of weights).  The generic 64 x 64-tile GEMM restages the
+// weights per tile and runs these at 0.7-1.9 TB/s.  Here a wave keeps the whole weight matrix as bf16 hi / lo MFMA B
+// fragments in registers (KS k16 steps x NTL column tiles), walks 32-row tiles of X with the next tile's rows requested
+// before the current tile's MFMAs (a lane reads 8 consecutive floats of its row: whole rows are contiguous, so a wave's
+// loads are one contiguous span), splits them into hi / lo in registers (the bf16_3x product lo x hi + hi x lo + hi x hi
+// of serl_gemm), and stores finished rows straight from the accumulators (32 consecutive floats of a row per half wave).
+template <int KS, int NTL>
+__global__ __launch_bounds__(256) void pw_stream_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float* __restrict__ y, int M, int K,
+                                                        int N, int act, int accumulate) {
+  const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+  // B fragments: lane (n = r, h) holds W[16 s + 8 h + j][32 t + r], j < 8
+  bf16x8_t bh[KS][NTL], bl[KS][NTL];
+  float bs[NTL];
+#pragma unroll
+  for (int t = 0; t < NTL; ++t) {
+    const int n = 32 * t + r;
+    bs[t] = n < N ? bias[n] : 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      u32x4_t hv, lv;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int k0 = 16 * s + 8 * h + 2 * e;
+        const float a = (k0 < K && n < N) ? w[(size_t)k0 * N + n] : 0.f;
+        const float b = (k0 + 1 < K && n < N) ? w[(size_t)(k0 + 1) * N + n] : 0.f;
+        uint32_t hh, ll;
+        split_pair(a, b, hh, ll);
+        hv[e] = hh; lv[e] = ll;
+      }
+      bh[s][t] = __builtin_bit_cast(bf16x8_t, hv);
+      bl[s][t] = __builtin_bit_cast(bf16x8_t, lv);
+    }
+  }
+  const int ntiles = (M + 31) / 32;
+  // A rows of a tile: lane (row r, h), step s: floats [16 s + 8 h, + 8) of row 32 tile + r.  Unconditional loads from a
+  // clamped address, no mask behind them (a select right behind a load makes hipcc wait for it at once): columns past K
+  // meet zero weights, rows past M are not stored -- what is read instead is finite activation data.
+  auto load_a = [&](int tile, float4 (&v)[KS][2]) {
+    const int m = tile * 32 + r;
+    const float* row = x + (size_t)((tile < ntiles && m < M) ? m : 0) * K;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int k0 = 16 * s + 8 * h;
+      const float4* p = reinterpret_cast<const float4*>(row + (k0 < K ? k0 : 0));
+      v[s][0] = p[0]; v[s][1] = p[1];
+    }
+  };
+  float4 cur[KS][2], nxt[KS][2];
+  load_a(wave, cur);
+  for (int tile = wave; tile < ntiles; tile += nwaves) {
+    load_a(tile + nwaves, nxt);
+    f32x16 acc[NTL];
+#pragma unroll
+    for (int t = 0; t < NTL; ++t)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      u32x4_t hv, lv;
+      uint32_t hh, ll;
+      split_pair(cur[s][0].x, cur[s][0].y, hh, ll); hv[0] = hh; lv[0] = ll;
+      split_pair(cur[s][0].z, cur[s][0].w, hh, ll); hv[1] = hh; lv[1] = ll;
+      split_pair(cur[s][1].x, cur[s][1].y, hh, ll); hv[2] = hh; lv[2] = ll;
+      split_pair(cur[s][1].z, cur[s][1].w, hh, ll); hv[3] = hh; lv[3] = ll;
+      const bf16x8_t ah = __builtin_bit_cast(bf16x8_t, hv), al = __builtin_bit_cast(bf16x8_t, lv);
+#pragma unroll
+      for (int t = 0; t < NTL; ++t) {
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[s][t], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[s][t], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[s][t], acc[t], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) {
+      const int n = 32 * t + r;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int m = tile * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+        if (m < M && n < N) {
+          float v = act_apply(acc[t][q] + bs[t], act);
+          float* dst = y + (size_t)m * N + n;
+          if (accumulate) v += *dst;
+          *dst = v;
+        }
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) { cur[s][0] = nxt[s][0]; cur[s][1] = nxt[s][1]; }
+  }
+}
+
+template <int KS, int NTL>
+int pw_stream_launch(const float* x, const float* w, const float* b, float* y, long long M, int K, int N, int act,
+                     int accumulate, hipStream_t st) {
+  const int ntiles = (int)((M + 31) / 32);
+  int blocks = (ntiles + 3) / 4;
+  if (blocks > 256 * 8) blocks = 256 * 8;       // 8 blocks of 4 waves per CU, each wave walks its tiles with a stride
+  hipLaunchKernelGGL((pw_stream_kernel<KS, NTL>), dim3(blocks), dim3(256), 0, st, x, w, b, y, (int)M, K, N, act, accumulate);
+  SERL_CHECK_LAUNCH("mbv3 pointwise (streaming)");
+  return SERL_OK;
+}
+
 // pointwise convolution / dense layer: Y (M, N) [+]= act(X (M, K) W (K, N) + bias)
 int pointwise(const float* x, const float* w, const float* b, float* y, long long M, int K, int N, int act, int accumulate,
               hipStream_t st) {
   SERL_CHECK_ARG(M * (long long)(K > N ? K : N) < (1ll << 31), "mobilenet: chunk too large for 32-bit tensor offsets");
+  // (chosen by K and N only, never by M: a batch computed in chunks must give the bits of the whole batch)
+  static const bool stream_ok = getenv("SERL_AMD_MBV3_STREAM") == nullptr || strcmp(getenv("SERL_AMD_MBV3_STREAM"), "0") != 0;   // A/B switch
+  if (stream_ok && serl_get_matmul_precision() == 1 && K % 8 == 0 && K <= 80 && N <= 96 && act != ACT_HSIGMOID &&
+      (((uintptr_t)x | (uintptr_t)y) & 15) == 0) {
+    const int ks = (K + 15) / 16, ntl = (N + 31) / 32;
+#define PW_CASE(KS_, NTL_) if (ks == KS_ && ntl == NTL_) return pw_stream_launch<KS_, NTL_>(x, w, b, y, M, K, N, act, accumulate, st);
+    PW_CASE(1, 1) PW_CASE(1, 2) PW_CASE(2, 1) PW_CASE(2, 3) PW_CASE(3, 1) PW_CASE(3, 2) PW_CASE(4, 1) PW_CASE(5, 1) PW_CASE(5, 2)
+#undef PW_CASE
+  }
   return serl_gemm(x, w, y, b, 1, (int)M, N, K, K, 0, 0, K, 1, 0, 0, N, 1, 0, N, 0, 1, 0, act, accumulate, 1, 1, st);
 }
 

@@ -17,7 +17,10 @@ def test_layout_matches_the_library():
     assert pm._offsets()[1] == _lib.load().serl_mbv3_param_floats()
 
 
-@pytest.mark.parametrize("case", [(3, 128, 128, "u8"), (2, 128, 128, "f32"), (2, 96, 80, "u8"), (1, 224, 224, "f32")])
+# (8 images of 128 x 128: every layer of the first four blocks has >= 2048 rows, i.e. runs on the streaming pointwise kernel
+#  at "bf16_3x" -- all of its (k16 steps, column tiles) instantiations)
+@pytest.mark.parametrize("case", [(3, 128, 128, "u8"), (2, 128, 128, "f32"), (2, 96, 80, "u8"), (1, 224, 224, "f32"),
+                                  (8, 128, 128, "u8")])
 def test_backbone_matches_oracle(dev, case, prec):
     from oracle import mobilenet as om
     from serl_amd.networks.mobilenet import Backbone
