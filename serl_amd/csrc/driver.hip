@@ -1275,7 +1275,9 @@ int augment_side(serl_learner* h, const serl_pixel_source* pixels, int side, con
 int backbone_side(serl_learner* h, int side, int n, Workspace& ws, hipStream_t st, Feats& f) {
   const Cfg& c = h->cfg;
   SERL_CHECK_ARG(h->backbone, "learner_update: serl_learner_set_backbone has not been called");
-  const int chunk = std::min(n, 256);
+  // images per launch chain: the layers behind the third stride have 64..16 rows per image, and at 256 images their
+  // launches are latency-bound (1.85 ms per 256 images; 512: 1.53, 1024: 1.43, 2048: 1.40); 1.9 MB of workspace per image
+  const int chunk = std::min(n, 1024);
   const long long wsb = serl_mbv3_workspace_bytes(chunk, c.H, c.W);
   WSF(ws, st, bbws, (size_t)wsb / 4, "bb_ws");
   const size_t fsz = (size_t)c.fh * c.fw * c.fc, img1 = (size_t)c.H * c.W * 3;
@@ -1630,7 +1632,8 @@ extern "C" int serl_learner_update(serl_learner* h, const serl_agent_buffers* ag
       DRV(features(h, ps, 2, f, lo, B, ws, st, 'C', h->fork_ev, true));
     }
     DRV(phase(h, "features_fwd", st));
-    // start pass i+1 when the main stream leaves its (HBM-bound) encoder forward
+    // start pass i+1 when the main stream leaves its encoder forward (round 3, re-measured with the fused kernels: behind
+    // the TD loss instead -1.3 %, in front of the encoder forward -16 % -- two persistent grids then share every CU's LDS)
     DRV(link(st, sta, h->agate));
     if (i + 1 < utd) DRV(enqueue_actor(i + 1));
     else DRV(enqueue_actor_obs());

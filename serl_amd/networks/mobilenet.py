@@ -75,7 +75,7 @@ def fold_batchnorm(kernel, scale, bias, mean, var, eps=1e-3):
 
 class Backbone:
     """The frozen feature extractor: flat device parameters + forward."""
-    CHUNK = 256          # images per launch sequence (bounds the activation workspace: ~1.9 MB per 128x128 image)
+    CHUNK = 1024         # images per launch sequence (bounds the activation workspace: ~1.9 MB per 128x128 image)
 
     def __init__(self, flat):
         self.flat = flat
