@@ -73,8 +73,10 @@ int serl_convs_fwd(int ngroups, const void* const* x, const void* const* wf, con
  * weight matrix in registers;
  * bit-identical output).  enable = 0 keeps every layer on the im2col kernels -- for A/B measurements and the bit-identity
  * test of the paths; 2 = without the 4-wave kernels; 3 = plus the LDS-DMA ring GEMM (csrc/sgemm_ring.h) for the deep
- * layers; 4 = serl_convs_fwd12 on its one-set kernel (default: two wave sets half a period apart).  Process-wide; no counterpart in the reference (XLA picks its convolution algorithm itself,
- * two_d4pg_encoder.py:30-38). */
+ * layers; 4 = serl_convs_fwd12 on its one-set kernel (default: two wave sets half a period apart); 5 / 6 / 7 = as 1 but
+ * serl_convs_dgrad_wgrad1_supported / serl_convs_fwd12_keep_supported answer 0 / the C = 64 -> F = 128 weight gradient stays
+ * on the im2col kernel (A/B of the round-3 kernels).  Process-wide; no counterpart in the reference (XLA picks its
+ * convolution algorithm itself, two_d4pg_encoder.py:30-38). */
 int serl_convs_set_patch_kernels(int enable);
 /* Persistent patch kernels launched after this call spread over at most `cus` compute units (0: all).  The step driver
  * brackets the actor's run-ahead pass with it (SERL_AMD_ACTOR_CUS).  Per calling thread (thread-local: a thread that
