@@ -708,9 +708,9 @@ def test_full_size_patch_vs_im2col_update(dev):
     """The headline shapes (2 x 128^2 cameras, stack 3, E1 encoder, batch 256, 10/2 critics) through update() with the
     LDS-patch kernels (default) and with the im2col kernels they replace (serl_convs_set_patch_kernels(0)), from the same
     agent and batch: at this size every persistent patch block walks many items.  The patch forward / data-gradient
-    kernels are bit-identical to im2col and the weight gradients of conv1 (fused into conv2's data gradient) and conv2 only
-    sum their pixels in another order, so after ONE critic step every gradient leaf except the first two conv layers' kernel /
-    bias must hold the same bits and those must agree to the weight gradient's 2e-5 summation tolerance; after the one-step call the logged scalars agree to 1e-5,
+    kernels are bit-identical to im2col and the weight gradients of conv1 (fused into conv2's data gradient), conv2 and conv3
+    only sum their pixels in another order, so after ONE critic step every gradient leaf except the first three conv layers'
+    kernel / bias must hold the same bits and those must agree to the weight gradient's 2e-5 summation tolerance; after the one-step call the logged scalars agree to 1e-5,
     after a two-step call to 2e-4 (Adam's sign-like first step may move a weight whose gradient is summation noise by 2 lr: parameters
     are bounded like everywhere else in this file)."""
     from serl_amd import ops
@@ -742,14 +742,15 @@ def test_full_size_patch_vs_im2col_update(dev):
     nsummed = 0
     for path in g0:
         a, b = g1[path], g0[path]
-        # first and second conv layer of camera 1 / camera 2 (two_d4pg_encoder.py:30-38): conv2's patch weight gradient and
-        # conv1's weight gradient inside conv2's data gradient (serl_convs_dgrad_wgrad1) sum their pixels per persistent block
-        if path[-2] in ("Conv_0", "Conv_1", "Conv_4", "Conv_5"):
+        # first three conv layers of camera 1 / camera 2 (two_d4pg_encoder.py:30-38): the patch weight gradients of conv2 and
+        # conv3 and conv1's weight gradient inside conv2's data gradient (serl_convs_dgrad_wgrad1) sum their pixels per
+        # persistent block
+        if path[-2] in ("Conv_0", "Conv_1", "Conv_2", "Conv_4", "Conv_5", "Conv_6"):
             nsummed += 1
             assert np.abs(a - b).max() <= 2e-5 * max(float(np.abs(b).max()), 1e-12), f"{'/'.join(path)}"
         else:
             assert np.array_equal(a, b), f"gradient leaf {'/'.join(path)} differs between patch and im2col kernels"
-    assert nsummed == 8
+    assert nsummed == 12
     # the actor step runs on the critic AFTER its Adam step (sac_learner.py:235), i.e. behind conv2's re-ordered sums
     assert_tree_close(res[1][0]["actor_grads"], res[0][0]["actor_grads"], rtol=5e-4, what="actor grads")
     for k in res[0][1]:
