@@ -155,6 +155,9 @@ int serl_sle_bwd(int ngroups, const float* const* dout, int ldo, const float* co
  * convolution: features (n, ceil(H/32), ceil(W/32), 960) fp32 NHWC.  params: one flat fp32 buffer of
  * serl_mbv3_param_floats() floats, leaves in forward order, each 64-float aligned (serl_amd/networks/mobilenet.py).
  * images: (n,H,W,3) uint8 (divided by 255 on load) or float already in [0,1]; ImageNet normalisation is applied on load. */
+/* 1 (default): the high-resolution blocks run 1x1 expand + depthwise conv as one kernel (the expanded tensor stays in LDS;
+ * same bits as the two launches); 0: two launches.  Process-wide, for A/B measurements and the bit-identity test. */
+int serl_mbv3_set_fused(int enable);
 long long serl_mbv3_param_floats(void);
 int serl_mbv3_feature_shape(int H, int W, int* fh, int* fw, int* fc);
 long long serl_mbv3_workspace_bytes(int n, int H, int W);

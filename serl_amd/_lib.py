@@ -71,6 +71,7 @@ _SIGS = {
     "serl_convs_wgrad_noalloc_max_bytes": [],
     "serl_convs_set_patch_kernels": [c_i],
     "serl_convs_set_cu_limit": [c_i],
+    "serl_mbv3_set_fused": [c_i],
     "serl_convs_fwd12_supported": [c_i, c_i, c_i, c_i, c_i],
     "serl_convs_fwd12": [c_i, PP, PP, PP, PP, PP, PP, c_i, c_i, c_i, c_i, c_i, c_i, c_i, PP, c_p],
     "serl_convs_fwd12_keep_supported": [c_i, c_i, c_i, c_i, c_i],

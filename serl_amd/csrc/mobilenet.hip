@@ -59,9 +59,10 @@ struct StemArgs {
   int n, H, W, OH, OW, pt, pl, in_u8;
 };
 __global__ __launch_bounds__(256) void stem_kernel(const StemArgs a) {
-  __shared__ float sw[27 * STEM_CH + STEM_CH];
-  for (int i = threadIdx.x; i < 27 * STEM_CH + STEM_CH; i += 256) sw[i] = i < 27 * STEM_CH ? a.w[i] : a.b[i - 27 * STEM_CH];
-  __syncthreads();
+  // the 432 weights are read with uniform indices straight from memory: scalar loads, an SGPR operand per FMA (from an
+  // LDS copy every FMA cost a broadcast ds_read: 184 us per 1024 images against 268 MB of output)
+  const float* __restrict__ sw = a.w;
+  const float* __restrict__ sb = a.b;
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   const long long total = (long long)a.n * a.OH * a.OW;
   if (idx >= total) return;
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const StemArgs a) {
   const float mean[3] = {0.485f, 0.456f, 0.406f}, std[3] = {0.229f, 0.224f, 0.225f};
   float acc[STEM_CH];
 #pragma unroll
-  for (int f = 0; f < STEM_CH; ++f) acc[f] = sw[27 * STEM_CH + f];
+  for (int f = 0; f < STEM_CH; ++f) acc[f] = sb[f];
   for (int ky = 0; ky < 3; ++ky) {
     const int iy = oy * 2 + ky - a.pt;
     if (iy < 0 || iy >= a.H) continue;   // zero padding applies to the NORMALISED image
@@ -256,6 +257,218 @@ int pw_stream_launch(const float* x, const float* w, const float* b, float* y, l
   return SERL_OK;
 }
 
+// ---- 1x1 expand + depthwise k x k in one kernel for the high-resolution blocks: the expanded tensor (4x / 3x the block's
+// input, the largest tensors of the network: 1.07 GB per 1024 images in block 1) is never written to memory.  A block
+// of 4 waves owns a TO x TO tile of depthwise OUTPUT pixels of one image: (i) its TI x TI input pixels (TI = (TO - 1) S +
+// KK, halo included) are expanded on the matrix cores exactly as pw_stream_kernel does (same fragments, same k order: the
+// same bits) and written, bias + activation applied, to an LDS tile [pixel][Cexp]; (ii) thread = (output pixel, 4
+// channels) runs dw_kernel's loop over the taps on that tile; pixels outside the image hold zeros there (the padding of
+// the depthwise conv), which add nothing, where dw_kernel skips the tap.  Same values as the two launches.
+template <int K_, int CE_, int KK, int S, int TO>
+struct EdCfg {      // K_ input channels, CE_ expanded channels: compile-time, so that every index split is a constant division
+  static constexpr int KS = (K_ + 15) / 16, NTL = (CE_ + 31) / 32;
+  static constexpr int TI = (TO - 1) * S + KK, NPIX = TI * TI, MT = (NPIX + 31) / 32;
+};
+struct EdArgs {
+  const float* x; const float* we; const float* be; const float* wd; const float* bd; float* y;
+  int n, H, W, K, CE, OH, OW, pt, pl, act, tiles_x, tiles_y;
+};
+template <int K_, int CE_, int KK, int S, int TO, int ACT>
+__global__ __launch_bounds__(256) void exp_dw_kernel(const EdArgs a) {
+  typedef EdCfg<K_, CE_, KK, S, TO> G;
+  constexpr int TI = G::TI, NPIX = G::NPIX, MT = G::MT, KS = G::KS, NTL = G::NTL;
+  extern __shared__ __attribute__((aligned(16))) float ed_smem[];
+  constexpr int CE = CE_, C4 = CE / 4, K = K_;
+  float* const E = ed_smem;                              // [NPIX][CE]
+  // depthwise weights [KK * KK][CE], then the bias [CE]: staged in LDS when two blocks per CU still fit with them,
+  // else read from global memory (12 KB, L1-resident)
+  constexpr bool WLDS = 2 * (NPIX * CE + (KK * KK + 1) * CE) * 4 <= 160 * 1024 || 2 * NPIX * CE * 4 > 160 * 1024;
+  float* const Wl = ed_smem + NPIX * CE;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, r = lane & 31, h = lane >> 5;
+  if (WLDS)
+    for (int i = tid; i < (KK * KK + 1) * CE; i += 256) Wl[i] = i < KK * KK * CE ? a.wd[i] : a.bd[i - KK * KK * CE];
+  const float* const Wd = WLDS ? Wl : a.wd;
+  const float* const Bd = WLDS ? Wl + KK * KK * CE : a.bd;
+  // expand weights as B fragments: lane (n = r, h) holds W[16 s + 8 h + j][32 t + r], j < 8 (as pw_stream_kernel)
+  bf16x8_t bh[KS][NTL], bl[KS][NTL];
+  float bs[NTL];
+#pragma unroll
+  for (int t = 0; t < NTL; ++t) {
+    const int n = 32 * t + r;
+    bs[t] = n < CE ? a.be[n] : 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      u32x4_t hv, lv;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int k0 = 16 * s + 8 * h + 2 * e;
+        const float w0 = (k0 < K && n < CE) ? a.we[(size_t)k0 * CE + n] : 0.f;
+        const float w1 = (k0 + 1 < K && n < CE) ? a.we[(size_t)(k0 + 1) * CE + n] : 0.f;
+        uint32_t hh, ll;
+        split_pair(w0, w1, hh, ll);
+        hv[e] = hh; lv[e] = ll;
+      }
+      bh[s][t] = __builtin_bit_cast(bf16x8_t, hv);
+      bl[s][t] = __builtin_bit_cast(bf16x8_t, lv);
+    }
+  }
+  const int ntiles = a.n * a.tiles_y * a.tiles_x;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int img = tile / (a.tiles_y * a.tiles_x), trem = tile - img * (a.tiles_y * a.tiles_x);
+    const int ty = trem / a.tiles_x, tx = trem - ty * a.tiles_x;
+    const int iy0 = ty * TO * S - a.pt, ix0 = tx * TO * S - a.pl;
+    const float* ximg = a.x + (size_t)img * a.H * a.W * K;
+    const bool interior = iy0 >= 0 && ix0 >= 0 && iy0 + TI <= a.H && ix0 + TI <= a.W;       // block-uniform
+    __syncthreads();                                       // the previous tile's depthwise reads (and the weight staging) are done
+    // ---- (i) expand: M tile = 32 of the tile's input pixels (row-major TI x TI), wave w takes M tiles w, w + 4, ...; the
+    // rows of all of them are requested first (one memory round trip per tile and wave, not one per M tile)
+    constexpr int MPW = (MT + 3) / 4;
+    float4 av[MPW][KS][2];
+#pragma unroll
+    for (int j = 0; j < MPW; ++j) {
+      const int m = min((wid + 4 * j) * 32 + r, NPIX - 1);
+      const int my = m / TI, mx = m - my * TI;
+      const int iy = min(max(iy0 + my, 0), a.H - 1), ix = min(max(ix0 + mx, 0), a.W - 1);   // clamped: valid memory, value unused
+      const float* row = ximg + ((size_t)iy * a.W + ix) * K;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const int k0 = 16 * s + 8 * h;
+        const float4* p = reinterpret_cast<const float4*>(row + (k0 < K ? k0 : 0));
+        av[j][s][0] = p[0]; av[j][s][1] = p[1];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < MPW; ++j) {
+      const int mt = wid + 4 * j;
+      if (mt >= MT) break;                                  // wave-uniform
+      f32x16 acc[NTL];
+#pragma unroll
+      for (int t = 0; t < NTL; ++t)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const float4 v0 = av[j][s][0], v1 = av[j][s][1];
+        u32x4_t hv, lv;
+        uint32_t hh, ll;
+        split_pair(v0.x, v0.y, hh, ll); hv[0] = hh; lv[0] = ll;
+        split_pair(v0.z, v0.w, hh, ll); hv[1] = hh; lv[1] = ll;
+        split_pair(v1.x, v1.y, hh, ll); hv[2] = hh; lv[2] = ll;
+        split_pair(v1.z, v1.w, hh, ll); hv[3] = hh; lv[3] = ll;
+        const bf16x8_t ah = __builtin_bit_cast(bf16x8_t, hv), al = __builtin_bit_cast(bf16x8_t, lv);
+#pragma unroll
+        for (int t = 0; t < NTL; ++t) {
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[s][t], acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[s][t], acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[s][t], acc[t], 0, 0, 0);
+        }
+      }
+      // rows past the tile's last pixel exist in the last M tile only (wave-uniform test), columns past CE in the last
+      // column tile only (compile-time): everything else is stored without a guard
+      float* const e0 = E + (mt * 32 + 4 * h) * CE + r;
+      if (!interior) {
+        // a tile that touches the image border: the zero padding of the depthwise conv applies to the EXPANDED tensor, so
+        // pixels outside the image are stored as zeros (the tap loop below then needs no tests: fmaf(0, w, acc) = acc)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int mm = mt * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+          const int my = mm / TI, mx = mm - my * TI;
+          const bool in = (unsigned)(iy0 + my) < (unsigned)a.H && (unsigned)(ix0 + mx) < (unsigned)a.W;
+#pragma unroll
+          for (int t = 0; t < NTL; ++t) acc[t][q] = in ? act_apply(acc[t][q] + bs[t], ACT) : 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < NTL; ++t)
+          if ((t + 1) * 32 <= CE || r < CE - t * 32) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+              if (mt * 32 + 32 <= NPIX || mt * 32 + (q & 3) + 8 * (q >> 2) + 4 * h < NPIX) e0[((q & 3) + 8 * (q >> 2)) * CE + 32 * t] = acc[t][q];
+          }
+      } else if (mt * 32 + 32 <= NPIX) {
+#pragma unroll
+        for (int t = 0; t < NTL; ++t)
+          if ((t + 1) * 32 <= CE || r < CE - t * 32) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) e0[((q & 3) + 8 * (q >> 2)) * CE + 32 * t] = act_apply(acc[t][q] + bs[t], ACT);
+          }
+      } else {
+#pragma unroll
+        for (int t = 0; t < NTL; ++t)
+          if ((t + 1) * 32 <= CE || r < CE - t * 32) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+              if (mt * 32 + (q & 3) + 8 * (q >> 2) + 4 * h < NPIX) e0[((q & 3) + 8 * (q >> 2)) * CE + 32 * t] = act_apply(acc[t][q] + bs[t], ACT);
+          }
+      }
+    }
+    __syncthreads();
+    // ---- (ii) depthwise: thread = (output pixel of the tile, 4 channels), dw_kernel's tap loop on the LDS tile (no
+    // per-tap tests: out-of-image pixels hold zeros)
+    for (int it = tid; it < TO * TO * C4; it += 256) {
+      const int c4 = it % C4, pxy = it / C4;
+      const int py = pxy / TO, px = pxy - py * TO;
+      const int oy = ty * TO + py, ox = tx * TO + px;
+      if (oy >= a.OH || ox >= a.OW) continue;
+      float4 acc = reinterpret_cast<const float4*>(Bd)[c4];
+      const float4* e0 = reinterpret_cast<const float4*>(E + ((py * S) * TI + px * S) * CE) + c4;
+      const float4* w0 = reinterpret_cast<const float4*>(Wd) + c4;
+#pragma unroll
+      for (int ky = 0; ky < KK; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < KK; ++kx) {
+          const float4 v = e0[(ky * TI + kx) * C4];
+          const float4 ww = w0[(ky * KK + kx) * C4];
+          acc.x = fmaf(v.x, ww.x, acc.x); acc.y = fmaf(v.y, ww.y, acc.y);
+          acc.z = fmaf(v.z, ww.z, acc.z); acc.w = fmaf(v.w, ww.w, acc.w);
+        }
+      reinterpret_cast<float4*>(a.y + (((size_t)img * a.OH + oy) * a.OW + ox) * CE)[c4] =
+          make_float4(act_apply(acc.x, ACT), act_apply(acc.y, ACT), act_apply(acc.z, ACT), act_apply(acc.w, ACT));
+    }
+  }
+}
+
+template <int K_, int CE_, int KK, int S, int TO, int ACT>
+int exp_dw_launch(EdArgs a, hipStream_t st) {
+  typedef EdCfg<K_, CE_, KK, S, TO> G;
+  a.tiles_x = cdiv(a.OW, TO); a.tiles_y = cdiv(a.OH, TO);
+  constexpr bool WLDS = 2 * (G::NPIX * CE_ + (KK * KK + 1) * CE_) * 4 <= 160 * 1024 || 2 * G::NPIX * CE_ * 4 > 160 * 1024;
+  const int lds = (G::NPIX * CE_ + (WLDS ? (KK * KK + 1) * CE_ : 0)) * 4;
+  static bool opted = false;
+  if (!opted) {
+    SERL_CHECK_HIP(hipFuncSetAttribute((const void*)exp_dw_kernel<K_, CE_, KK, S, TO, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+                   "mbv3 expand + depthwise");
+    opted = true;
+  }
+  SERL_CHECK_ARG(lds <= 160 * 1024, "mbv3 expand + depthwise: tile does not fit the LDS");
+  const long long ntiles = (long long)a.n * a.tiles_x * a.tiles_y;
+  // ~8 tiles per block: the set-up (weight fragments, depthwise weights) is amortised, and the blocks are fine-grained
+  // enough that the CUs finish together whatever number of them is resident
+  const int blocks = (int)std::min<long long>(ntiles, std::max<long long>(256 * 4, ntiles / 8));
+  hipLaunchKernelGGL((exp_dw_kernel<K_, CE_, KK, S, TO, ACT>), dim3(blocks), dim3(256), lds, st, a);
+  SERL_CHECK_LAUNCH("mbv3 expand + depthwise");
+  return SERL_OK;
+}
+
+int g_mbv3_fused = -1;      // serl_mbv3_set_fused (A/B and the bit-identity test); -1: SERL_AMD_MBV3_FUSE, default on
+// returns 1 when a fused kernel took the expand + depthwise pair of this block, 0 when the caller runs the two launches
+int expand_depthwise_fused(const float* x, const float* we, const float* be, const float* wd, const float* bd, float* y, int n,
+                           int H, int W, int K, int CE, int OH, int OW, int k, int s, int pt, int pl, int act, hipStream_t st,
+                           int* done) {
+  *done = 0;
+  if (g_mbv3_fused < 0) g_mbv3_fused = getenv("SERL_AMD_MBV3_FUSE") == nullptr || strcmp(getenv("SERL_AMD_MBV3_FUSE"), "0") != 0;
+  if (!g_mbv3_fused || serl_get_matmul_precision() != 1 || K % 8 != 0 || CE % 4 != 0 || act == ACT_HSIGMOID) return SERL_OK;
+  EdArgs a{x, we, be, wd, bd, y, n, H, W, K, CE, OH, OW, pt, pl, act, 0, 0};
+  *done = 1;
+  if (act == ACT_RELU) {
+    if (K == 16 && CE == 64 && k == 3 && s == 2) return exp_dw_launch<16, 64, 3, 2, 8, ACT_RELU>(a, st);     // block 1
+    if (K == 24 && CE == 72 && k == 3 && s == 1) return exp_dw_launch<24, 72, 3, 1, 8, ACT_RELU>(a, st);     // block 2
+    if (K == 24 && CE == 72 && k == 5 && s == 2) return exp_dw_launch<24, 72, 5, 2, 4, ACT_RELU>(a, st);     // block 3
+    if (K == 40 && CE == 120 && k == 5 && s == 1) return exp_dw_launch<40, 120, 5, 1, 8, ACT_RELU>(a, st);   // blocks 4, 5
+  }
+  *done = 0;
+  return SERL_OK;
+}
+
 // pointwise convolution / dense layer: Y (M, N) [+]= act(X (M, K) W (K, N) + bias)
 int pointwise(const float* x, const float* w, const float* b, float* y, long long M, int K, int N, int act, int accumulate,
               hipStream_t st) {
@@ -323,6 +536,10 @@ int plan(int H, int W, Plan* pl) {
 
 }  // namespace
 
+extern "C" int serl_mbv3_set_fused(int enable) {
+  g_mbv3_fused = enable ? 1 : 0;
+  return SERL_OK;
+}
 extern "C" long long serl_mbv3_param_floats(void) {
   Offsets o;
   return layout(&o);
@@ -374,14 +591,19 @@ extern "C" int serl_mbv3_forward(const float* params, const void* images, int in
     const long long M = (long long)n * h * w;
     const float* xin = X[cur];
     const float* dwin = xin;
-    if (b.ir) {
-      if (int e = pointwise(xin, params + o.exp_k[i], params + o.exp_b[i], E, M, cin, b.exp, b.act, 0, st)) return e;
-      dwin = E;
-    }
     int oh, ow;
     same_pad(h, b.k, b.s, &pt, &oh);
     same_pad(w, b.k, b.s, &pl_, &ow);
-    {
+    int fused = 0;
+    if (b.ir) {
+      if (int e = expand_depthwise_fused(xin, params + o.exp_k[i], params + o.exp_b[i], params + o.dw_k[i], params + o.dw_b[i],
+                                         D, n, h, w, cin, b.exp, oh, ow, b.k, b.s, pt, pl_, b.act, st, &fused)) return e;
+    }
+    if (b.ir && !fused) {
+      if (int e = pointwise(xin, params + o.exp_k[i], params + o.exp_b[i], E, M, cin, b.exp, b.act, 0, st)) return e;
+      dwin = E;
+    }
+    if (!fused) {
       DwArgs a{dwin, params + o.dw_k[i], params + o.dw_b[i], D, n, h, w, b.exp / 4, oh, ow, b.k, b.s, pt, pl_, b.act};
       const long long total = (long long)n * oh * ow * (b.exp / 4);
       hipLaunchKernelGGL(dw_kernel, dim3((unsigned)cdivll(total, 256)), dim3(256), 0, st, a);

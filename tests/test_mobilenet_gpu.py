@@ -40,6 +40,29 @@ def test_backbone_matches_oracle(dev, case, prec):
     assert np.abs(got - want).max() <= tol, (np.abs(got - want).max(), scale)
 
 
+@pytest.mark.parametrize("case", [(3, 128, 128), (2, 96, 80), (1, 70, 52), (9, 128, 128)])
+def test_backbone_fused_expand_depthwise_bit_identical(dev, case):
+    """The high-resolution blocks' 1x1 expand + depthwise conv in one kernel (expanded tensor in LDS) against the two
+    launches: same fragments, same k order, same tap loop -> the same bits, for full and ragged tiles, odd sizes with
+    asymmetric SAME padding and several images per persistent block."""
+    from serl_amd import _lib
+    from serl_amd.networks.mobilenet import Backbone
+    n, H, W = case
+    bb = Backbone.synthetic(5)
+    x = torch.randint(0, 256, (n, H, W, 3), dtype=torch.uint8, device=dev)
+    lib = _lib.load()
+    try:
+        lib.serl_mbv3_set_fused(0)
+        ref = bb.forward(x).clone()
+        lib.serl_mbv3_set_fused(1)
+        got = bb.forward(x)
+        torch.cuda.synchronize()
+    finally:
+        lib.serl_mbv3_set_fused(1)
+    assert torch.isfinite(got).all() and float(got.abs().max()) > 1e-3
+    assert torch.equal(got, ref)
+
+
 def test_backbone_chunks_and_from_tree(dev):
     from serl_amd.networks.mobilenet import Backbone
     bb = Backbone.synthetic(1)
