@@ -152,7 +152,7 @@ def load():
     lib.serl_last_error.argtypes = []
     lib.serl_last_error.restype = C.c_char_p
     _lib = lib
-    if os.environ.get("SERL_AMD_CONV_PATCH") in ("0", "2", "3", "4", "5", "6", "7"):   # A/B measurements (serl_convs_set_patch_kernels)
+    if os.environ.get("SERL_AMD_CONV_PATCH") in ("0", "2", "3", "4", "5", "6", "7", "8"):   # A/B measurements (serl_convs_set_patch_kernels)
         lib.serl_convs_set_patch_kernels(int(os.environ["SERL_AMD_CONV_PATCH"]))
     env = os.environ.get("SERL_AMD_MATMUL_PRECISION")
     if env is not None:

@@ -10,6 +10,7 @@
 #include "sgemm.h"
 #include "pconv.h"
 #include "pconv_dgw1.h"
+#include "pconv4.h"
 #include "sgemm_ring.h"
 
 typedef unsigned short ushort_t;
@@ -357,7 +358,7 @@ __global__ __launch_bounds__(256) void merge_kernel(const ushort_t* __restrict__
 // HWIO fp32 kernel -> wf (S format [F][2][Kp], forward B operand) and wd (S format [(ky,kx,c)][2][F], dgrad B operand)
 struct PrepArgs {
   const float* w[MAXG]; ushort_t* wf[MAXG]; ushort_t* wd[MAXG];
-  int KH, KWC, F, Kp, pad32;
+  int KH, KWC, F, Kp, pad32, wq4;    // wq4: the layer is the last encoder layer's shape -- also write pconv4.h's fragment-ordered image behind wf
 };
 __global__ __launch_bounds__(256) void prep_weights_kernel(const PrepArgs a) {
   // tile = 32 k' x 32 f: read and the wd write run along f, the wf write runs along k' (transposed through LDS)
@@ -382,6 +383,11 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(const PrepArgs a) {
         a.wd[gi][(size_t)(k * 2) * a.F + f] = h;
         a.wd[gi][(size_t)(k * 2 + 1) * a.F + f] = l;
       }
+      if (a.wq4) {
+        ushort_t* wq = a.wf[gi] + (size_t)2 * a.Kp * a.F;
+        wq[p4_wq_index(k, f, 0)] = h;
+        wq[p4_wq_index(k, f, 1)] = l;
+      }
     }
     th[ty + 8 * i][tx] = h; tl[ty + 8 * i][tx] = l;
   }
@@ -401,7 +407,7 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(const PrepArgs a) {
 #define PREP_MAX_JOBS 32
 struct PrepJobs {
   const float* w[PREP_MAX_JOBS]; ushort_t* wf[PREP_MAX_JOBS]; ushort_t* wd[PREP_MAX_JOBS];
-  int KH[PREP_MAX_JOBS], KWC[PREP_MAX_JOBS], F[PREP_MAX_JOBS], Kp[PREP_MAX_JOBS], pad32[PREP_MAX_JOBS];
+  int KH[PREP_MAX_JOBS], KWC[PREP_MAX_JOBS], F[PREP_MAX_JOBS], Kp[PREP_MAX_JOBS], pad32[PREP_MAX_JOBS], wq4[PREP_MAX_JOBS];
 };
 __global__ __launch_bounds__(256) void prep_weights_multi_kernel(const PrepJobs a) {
   __shared__ unsigned short th[32][33], tl[32][33];
@@ -427,6 +433,11 @@ __global__ __launch_bounds__(256) void prep_weights_multi_kernel(const PrepJobs 
       if (wd != nullptr) {
         wd[(size_t)(k * 2) * F + f] = h;
         wd[(size_t)(k * 2 + 1) * F + f] = l;
+      }
+      if (a.wq4[j]) {
+        ushort_t* wq = wf + (size_t)2 * Kp * F;
+        wq[p4_wq_index(k, f, 0)] = h;
+        wq[p4_wq_index(k, f, 1)] = l;
       }
     }
     th[ty + 8 * i][tx] = h; tl[ty + 8 * i][tx] = l;
@@ -522,8 +533,10 @@ static bool all_aligned16(const void* const* ps, int n) {
 
 static int s_kp(int in_u8, int KH, int KW, int C) { return in_u8 ? KH * 32 : KH * KW * C; }
 
+// the last encoder layer's shape keeps a second image of its weights (pconv4.h: fragment order of pconv4_fwd_kernel) behind wf
+static bool s_wq4(int in_u8, int KH, int KW, int C, int F) { return !in_u8 && KH == 3 && KW == 3 && C == 128 && F == 256; }
 extern "C" long long serl_convs_weight_bytes(int in_u8, int KH, int KW, int C, int F) {
-  return 4ll * s_kp(in_u8, KH, KW, C) * F;
+  return 4ll * s_kp(in_u8, KH, KW, C) * F * (s_wq4(in_u8, KH, KW, C, F) ? 2 : 1);
 }
 
 extern "C" int serl_split_f32(const float* in, void* out, long long rows, int cols, void* stream) {
@@ -546,7 +559,7 @@ extern "C" int serl_convs_prep_weights(int ngroups, const float* const* w, void*
   SERL_CHECK_ARG(KH > 0 && KW > 0 && C > 0 && F > 0 && F % 8 == 0, "convs_prep_weights: F must be a multiple of 8");
   SERL_CHECK_ARG(in_u8 ? (KW * C >= 8 && KW * C <= 32) : C % 8 == 0, "convs_prep_weights: need C %% 8 == 0 (or 8 <= KW*C <= 32 for uint8 input)");
   PrepArgs a;
-  a.KH = KH; a.KWC = KW * C; a.F = F; a.Kp = s_kp(in_u8, KH, KW, C); a.pad32 = in_u8;
+  a.KH = KH; a.KWC = KW * C; a.F = F; a.Kp = s_kp(in_u8, KH, KW, C); a.pad32 = in_u8; a.wq4 = s_wq4(in_u8, KH, KW, C, F);
   for (int i = 0; i < ngroups; ++i) {
     SERL_CHECK_ARG(w[i] && wf[i], "convs_prep_weights: null pointer");
     a.w[i] = w[i]; a.wf[i] = (ushort_t*)wf[i]; a.wd[i] = wd ? (ushort_t*)wd[i] : nullptr;
@@ -570,6 +583,7 @@ extern "C" int serl_convs_prep_weights_multi(int njobs, const float* const* w, v
     SERL_CHECK_ARG(w[i] && wf[i], "convs_prep_weights_multi: null pointer");
     a.w[i] = w[i]; a.wf[i] = (ushort_t*)wf[i]; a.wd[i] = wd ? (ushort_t*)wd[i] : nullptr;
     a.KH[i] = KH[i]; a.KWC[i] = KW[i] * C[i]; a.F[i] = F[i]; a.Kp[i] = s_kp(in_u8[i], KH[i], KW[i], C[i]); a.pad32[i] = in_u8[i];
+    a.wq4[i] = s_wq4(in_u8[i], KH[i], KW[i], C[i], F[i]);
     gx = a.Kp[i] > gx ? a.Kp[i] : gx; gy = F[i] > gy ? F[i] : gy;
   }
   hipLaunchKernelGGL(prep_weights_multi_kernel, dim3(cdiv(gx, 32), cdiv(gy, 32), njobs), dim3(256), 0, (hipStream_t)stream, a);
@@ -587,11 +601,13 @@ extern "C" int serl_convs_prep_weights_multi(int njobs, const float* const* w, v
 // 5 = as 1 without the fused conv2-data-gradient + conv1-weight-gradient kernel (serl_convs_dgrad_wgrad1_supported says 0).
 // 7 = as 1 with conv3's weight gradient on the im2col kernel.
 // 6 = as 1 without the layer-1-keeping variant of the fused forward (serl_convs_fwd12_keep_supported says 0).
-static int g_patch_kernels = 1, g_ring_kernels = 0, g_wide_kernels = 1, g_f12_two_sets = 1, g_dgw1 = 1, g_f12_keep = 1, g_wgradw = 1;
+// 8 = as 1 with the last layer's forward (15 x 15 x 128 -> 7 x 7 x 256) on the im2col kernel instead of pconv4_fwd_kernel.
+static int g_patch_kernels = 1, g_ring_kernels = 0, g_wide_kernels = 1, g_f12_two_sets = 1, g_dgw1 = 1, g_f12_keep = 1, g_wgradw = 1, g_fwd4 = 1;
 extern "C" int serl_convs_set_patch_kernels(int enable) {
   g_patch_kernels = enable ? 1 : 0;
   g_ring_kernels = enable == 3 ? 1 : 0;
-  g_wide_kernels = enable == 1 || enable == 3 || enable == 4 ? 1 : 0;
+  g_wide_kernels = enable == 1 || enable >= 3 ? 1 : 0;
+  g_fwd4 = enable == 8 ? 0 : 1;
   g_f12_two_sets = enable == 4 ? 0 : 1;
   g_dgw1 = enable == 5 ? 0 : 1;
   g_f12_keep = enable == 6 ? 0 : 1;
@@ -608,6 +624,9 @@ extern "C" int serl_convs_set_cu_limit(int cus) {
   return SERL_OK;
 }
 
+#ifndef P4_PF
+#define P4_PF 8
+#endif
 #ifndef S_RING_FWD
 #define S_RING_FWD RingCfg<256, 128, 4, 2, 3>     // 8 waves, 64 x 64 per wave, three K slabs of 32 in flight
 #endif
@@ -631,6 +650,15 @@ extern "C" int serl_convs_fwd(int ngroups, const void* const* x, const void* con
     const bool fit32 = C == 32 && F == 64 && g.OW <= 32 && (IW + 1) / 2 <= 32;
     // C = 64 -> 128 at OW <= 16: four waves with the whole weight matrix in their registers (pconv_fwdw_kernel)
     const bool fit16 = g_wide_kernels && C == 64 && F == 128 && g.OW <= 16 && (IW + 1) / 2 <= 16;
+    if (g_wide_kernels && g_fwd4 && pconv4_fits(B, IH, IW, C, KH, KW, stride, F)) {
+      PConv4Args a;
+      a.B = B; a.relu = relu;
+      for (int i = 0; i < ngroups; ++i) {
+        a.x[i] = (const ushort_t*)x[i]; a.wq[i] = (const ushort_t*)wf[i] + (size_t)2 * 9 * C * F; a.bias[i] = bias[i];
+        a.y[i] = (ushort_t*)y[i]; a.rmask[i] = rmask ? (unsigned char*)rmask[i] : nullptr;
+      }
+      return pconv4_fwd_launch<P4Cfg<P4_PF>>(a, ngroups, st, "convs_fwd(last layer)");
+    }
     if (fit16) {
       PConvFwdArgs a;
       a.B = B; a.IH = IH; a.IW = IW; a.OH = g.OH; a.OW = g.OW; a.relu = relu;

@@ -1,0 +1,406 @@
+// Forward of the LAST encoder layer (3x3 stride 2, 15 x 15 x 128 -> 7 x 7 x 256) on S-format tensors.
+//
+// Neither operand of this layer fits on chip the way conv1-3's do: the weights are 1.18 MB (9 x 128 x 256 hi / lo
+// pairs), an image's input 115 KB.  The im2col kernel (sgemm_kernel<ConvFwdS>) gathers every tap from global memory and
+// re-streams the weights per 128-row tile: 3.05x the algorithmic bytes on the L2-miss side, 0.31 of the MFMA roof
+// (DESIGN.md 3a).  Here an item is TWO images (98 output pixels = four 32-row MFMA tiles, the last one nearly empty) and
+// the K loop is ordered by the PARITY CLASS of the input pixel a tap reads -- a 3x3 stride-2 tap (ky, kx) of output pixel
+// (oy, ox) reads input pixel (2 oy + ky, 2 ox + kx), so taps {0,2}x{0,2} only ever touch (even, even) pixels, {0,2}x{1}
+// (even, odd), {1}x{0,2} (odd, even) and (1,1) (odd, odd): every input pixel is needed by exactly one class, i.e. for one
+// contiguous stretch of the K loop, and the block fetches it exactly once:
+//
+//   K order: class (EE, EO, OE, OO) -> channel half (0..63, 64..127) -> tap of the class -> 16 channels
+//   (72 k16 steps in eight sub-phases of 16, 16, 8, 8, 8, 8, 4, 4 steps)
+//
+// * A operand: the pixels of a sub-phase (one class, 64 channels: full 128-byte lines of the hi and of the lo plane)
+//   come by LDS-DMA into a ring of four slots, three sub-phases ahead of their use, one DMA instruction or two per k16
+//   step; a record is 256 bytes + 16 bytes of padding (17 chunks: consecutive records start in consecutive 16-byte bank
+//   groups), so every fragment address is a per-lane base plus an immediate.
+// * B operand: the weights are pre-ordered by serl_convs_prep_weights into exactly the fragments a wave needs per k16
+//   step (p4_wq_index), and each of the four waves (one per SIMD, 64 output channels each, all four M tiles) streams its
+//   4 KB per step from L2 straight into registers, PF steps ahead: no LDS traffic, no barrier for the weights.  Blocks of
+//   one group run on the same XCDs, so that an XCD's L2 holds one group's weights.
+// * one barrier per sub-phase; the epilogue goes through a wave-private fp32 tile.
+//
+// The sums are the same products in a different order than the im2col kernel's (ky, kx, c): results agree to fp32
+// rounding (tests/test_kernels_gpu.py, 2e-6 of the output scale), not bit for bit.
+#pragma once
+#include <utility>
+#include "pconv.h"
+
+struct PConv4Args {
+  const unsigned short* x[MAXG];      // S format [B][15][15][2][128]
+  const unsigned short* wq[MAXG];     // fragment order (p4_wq_index)
+  const float* bias[MAXG];
+  unsigned short* y[MAXG];            // S format [B][7][7][2][256]
+  unsigned char* rmask[MAXG];
+  int B, relu, nitems, ngroups, gx, xcd_map;
+};
+
+constexpr int P4_NSTEP = 72;
+__host__ __device__ constexpr int p4_sp_len(int sp) { return sp < 2 ? 16 : (sp < 6 ? 8 : 4); }
+__host__ __device__ constexpr int p4_sp_start(int sp) { return sp < 2 ? 16 * sp : (sp < 6 ? 32 + 8 * (sp - 2) : 64 + 4 * (sp - 6)); }
+__host__ __device__ constexpr int p4_sp_of(int j) { return j < 32 ? j / 16 : (j < 64 ? 2 + (j - 32) / 8 : 6 + (j - 64) / 4); }
+// class cl = 2 (ky & 1) + (kx & 1): grid of its pixels, DMA instructions per wave and sub-phase (4 waves x 1 KB each)
+__host__ __device__ constexpr int p4_cls_w(int cl) { return (cl & 1) ? 7 : 8; }
+__host__ __device__ constexpr int p4_cls_h(int cl) { return (cl & 2) ? 7 : 8; }
+__host__ __device__ constexpr int p4_cls_np(int cl) { return p4_cls_w(cl) * p4_cls_h(cl); }
+__host__ __device__ constexpr int p4_cls_ni(int cl) { return (2 * p4_cls_np(cl) * 17 + 255) / 256; }      // 9, 8, 8, 7
+__host__ __device__ constexpr int p4_cls_d0(int cl) { return cl == 0 ? 0 : p4_cls_d0(cl - 1) + p4_cls_ni(cl - 1); }
+// k16 step that multiplies weight row (ky, kx, c)
+__host__ __device__ constexpr int p4_step_of_k(int ky, int kx, int c) {
+  return p4_sp_start((2 * (ky & 1) + (kx & 1)) * 2 + (c >> 6)) + ((ky >> 1) * ((kx & 1) ? 1 : 2) + (kx >> 1)) * 4 + ((c >> 4) & 3);
+}
+// position (in bf16 units) of weight (k = (ky * 3 + kx) * 128 + c, f) of a plane in the fragment-ordered image:
+// [step][wave = f / 64][n tile][plane][lane = 32 (k % 16 / 8) + f % 32][k % 8]
+__host__ __device__ inline long long p4_wq_index(int k, int f, int plane) {
+  const int tap = k >> 7, c = k & 127;
+  const int j = p4_step_of_k(tap / 3, tap % 3, c);
+  const int e = c & 15, lane = (e >> 3) * 32 + (f & 31);
+  return ((((long long)(j * 4 + (f >> 6)) * 2 + ((f >> 5) & 1)) * 2 + plane) * 64 + lane) * 8 + (e & 7);
+}
+
+template <int PF_>
+struct P4Cfg {
+  static constexpr int PF = PF_;                     // k16 steps of weight fragments in flight
+  static constexpr int B_IMG = 15 * 15 * 512;        // bytes of an input image
+  static constexpr int REC = 272;
+  static constexpr int SLOT0 = 0, SLOT1 = 36864, SLOT2 = 73728, SLOT3 = 106496, STAGE = 139264;
+  static constexpr int STAGE_W = 16 * 272;           // wave-private output tile: 16 rows x (64 + 4) floats
+  static constexpr int LDS = STAGE + 4 * STAGE_W;
+  static constexpr int NST = 28;                     // output stores per wave and item without the masks
+  static_assert(P4_NSTEP % PF == 0 && PF >= 2 && PF <= 8, "weight ring");
+  static_assert(LDS <= 160 * 1024, "LDS");
+  static_assert(p4_cls_ni(0) * 4096 <= SLOT1 - SLOT0 && p4_cls_ni(1) * 4096 <= SLOT3 - SLOT2 && p4_cls_ni(1) * 4096 <= STAGE - SLOT3, "slots");
+};
+__host__ __device__ constexpr int p4_slot_off(int slot) { return slot == 0 ? 0 : slot == 1 ? 36864 : slot == 2 ? 73728 : 106496; }
+
+template <int PF>
+struct P4Wave {
+  f32x16 acc[4][2];
+  u32x4_t afr[2][4][2];        // [set][M tile][plane]
+  u32x4_t bfr[PF][4];          // [ring slot][n tile * 2 + plane]
+  uint32_t abase[4][4];        // [class][M tile]: LDS address of the lane's record for tap (0, 0) of the class, half 0
+  uint32_t doff[32];           // byte offsets (from the item's first image) of the chunks this lane copies, by class and instruction
+  const char* wq_base;         // this group's image (uniform)
+  uint32_t wq_voff;            // wave * 4096 + lane * 16
+  unsigned char* smem;
+  int wid;
+  const char* x0;
+};
+
+#define P4_LD(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(dst) : "v"(addr), "n"(imm) : "memory")
+
+// A fragments of step J into register set SET
+template <class G, int J, int SET>
+__device__ __forceinline__ void p4_load_a(P4Wave<G::PF>& S) {
+  constexpr int sp = p4_sp_of(J), cl = sp >> 1, half = sp & 1, t = J - p4_sp_start(sp);
+  constexpr int tp = t >> 2, s = t & 3;
+  constexpr int ntx = (cl & 1) ? 1 : 2;
+  constexpr int dy = tp / ntx, dx = tp % ntx;
+  constexpr int slot0 = (cl & 1) * 2;
+  constexpr int imm = half * (p4_slot_off(slot0 + 1) - p4_slot_off(slot0)) + (dy * p4_cls_w(cl) + dx) * G::REC + s * 32;
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    P4_LD(S.afr[SET][m][0], S.abase[cl][m], imm);
+    P4_LD(S.afr[SET][m][1], S.abase[cl][m], imm + 128);
+  }
+}
+
+// DMA instruction I (of this wave) of sub-phase TSP of the item whose first image starts at `ximg`
+template <class G, int TSP, int I>
+__device__ __forceinline__ void p4_dma(const P4Wave<G::PF>& S, const char* ximg) {
+  constexpr int tcl = TSP >> 1;
+  uint32_t o = S.doff[p4_cls_d0(tcl) + I];
+  asm volatile("" : "+v"(o));                 // (opaque: no hoisted 64-bit addresses)
+  const char* g = ximg + (TSP & 1) * 128 + (size_t)o;
+  __builtin_amdgcn_global_load_lds((pconv_gptr_t)g, (pconv_lptr_t)(S.smem + p4_slot_off(TSP & 3) + (I * 4 + S.wid) * 1024), 16, 0, 0);
+}
+template <class G, int TSP, int I0, int I1>
+__device__ __forceinline__ void p4_dma_range(const P4Wave<G::PF>& S, const char* ximg) {
+  if constexpr (I0 < I1) {
+    p4_dma<G, TSP, I0>(S, ximg);
+    p4_dma_range<G, TSP, I0 + 1, I1>(S, ximg);
+  }
+}
+
+// Weight fragments of step JB into ring slot SLOT.  By hand: with an LDS-DMA in flight hipcc waits vmcnt(0) at the first
+// use of a compiler-visible load, i.e. it drains the DMA and the fragments requested since once per ring revolution.
+// Issued and NOT waited for; p4_step's counted s_waitcnt names the registers.
+template <class G, int JB, int SLOT>
+__device__ __forceinline__ void p4_load_b(P4Wave<G::PF>& S) {
+#ifdef P4_B_SAME    // ablation build: every step's weight fragments from the first step's lines
+  const char* base = S.wq_base + (size_t)(JB & 1) * 16384;
+#else
+  const char* base = S.wq_base + (size_t)JB * 16384;          // uniform: an SGPR pair
+#endif
+  // (s_nop 4: hipcc may have produced `base` with v_readlane -- SGPRs it parked in a VGPR -- right before this statement, and
+  // its hazard recognizer does not look into inline asm: a VMEM instruction reading an SGPR that a VALU instruction wrote
+  // needs 5 wait states, or it addresses memory with the register's previous contents)
+  asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %4, %5 offset:0\n\tglobal_load_dwordx4 %1, %4, %5 offset:1024\n\t"
+               "global_load_dwordx4 %2, %4, %5 offset:2048\n\tglobal_load_dwordx4 %3, %4, %5 offset:3072"
+               : "=&v"(S.bfr[SLOT][0]), "=&v"(S.bfr[SLOT][1]), "=&v"(S.bfr[SLOT][2]), "=&v"(S.bfr[SLOT][3])
+               : "v"(S.wq_voff), "s"(base) : "memory");
+}
+
+// vector-memory instructions a wave issues in k16 step i (0 .. 71): the DMA share of the sub-phase three ahead, then 4
+// weight loads
+__host__ __device__ constexpr int p4_nd(int i) {
+  const int sp = p4_sp_of(i), t = i - p4_sp_start(sp), L = p4_sp_len(sp), N = p4_cls_ni(((sp + 3) & 7) >> 1);
+  return (t + 1) * N / L - t * N / L;
+}
+// ... issued after the weight loads of step T (T - PF .. : absolute step, negative = previous item) and before the waits
+// of step J; the output stores of the previous item (at least NST of them) lie between its step 71 and step 0.  vmcnt
+// retires in order, so "at most this many outstanding" = the fragments of step T have arrived (fewer is stricter).
+template <int PF, int NST>
+__host__ __device__ constexpr int p4_younger(int T, int J) {
+  int n = T - PF < 0 ? NST : 0;
+  for (int a = T - PF + 1; a < J; ++a) n += p4_nd((a + P4_NSTEP) % P4_NSTEP) + 4;
+  return n > 63 ? 63 : n;
+}
+
+template <class G, int... Js>
+__device__ __forceinline__ void p4_load_b_first(P4Wave<G::PF>& S, std::integer_sequence<int, Js...>) {
+  (p4_load_b<G, Js, Js>(S), ...);
+}
+
+template <class G, int J>
+__device__ __forceinline__ void p4_step(P4Wave<G::PF>& S, const char* xcur, const char* xnext) {
+  constexpr int PF = G::PF;
+  constexpr int sp = p4_sp_of(J), t = J - p4_sp_start(sp), L = p4_sp_len(sp);
+  constexpr bool last = t == L - 1;
+  constexpr int JN = (J + 1) % P4_NSTEP;
+  constexpr int SET = J & 1, SLOT = J % PF;
+  // this step's A fragments have arrived (requested one step ago), and its weight fragments (PF steps ago)
+  if constexpr (!last) {
+    asm volatile("s_waitcnt vmcnt(%12) lgkmcnt(0)"
+                 : "+v"(S.afr[SET][0][0]), "+v"(S.afr[SET][0][1]), "+v"(S.afr[SET][1][0]), "+v"(S.afr[SET][1][1]),
+                   "+v"(S.afr[SET][2][0]), "+v"(S.afr[SET][2][1]), "+v"(S.afr[SET][3][0]), "+v"(S.afr[SET][3][1]),
+                   "+v"(S.bfr[SLOT][0]), "+v"(S.bfr[SLOT][1]), "+v"(S.bfr[SLOT][2]), "+v"(S.bfr[SLOT][3])
+                 : "n"(p4_younger<PF, G::NST>(J, J)) : "memory");
+  } else {
+    // sub-phase boundary: wait for the NEXT step's weight fragments -- they were requested after the next sub-phase's
+    // DMA, so this wave's share of the next slot has landed too -- and this wave's reads of the current slot are done
+    asm volatile("s_waitcnt vmcnt(%12) lgkmcnt(0)"
+                 : "+v"(S.afr[SET][0][0]), "+v"(S.afr[SET][0][1]), "+v"(S.afr[SET][1][0]), "+v"(S.afr[SET][1][1]),
+                   "+v"(S.afr[SET][2][0]), "+v"(S.afr[SET][2][1]), "+v"(S.afr[SET][3][0]), "+v"(S.afr[SET][3][1]),
+                   "+v"(S.bfr[SLOT][0]), "+v"(S.bfr[SLOT][1]), "+v"(S.bfr[SLOT][2]), "+v"(S.bfr[SLOT][3])
+                 : "n"(p4_younger<PF, G::NST>(J + 1, J)) : "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  p4_load_a<G, JN, SET ^ 1>(S);
+  __builtin_amdgcn_sched_barrier(0);
+#ifndef P4_NO_MMA   // (ablation build)
+#pragma unroll
+  for (int p = 0; p < 3; ++p)
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+        S.acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, S.afr[SET][m][p == 0 ? 1 : 0]),
+                                                               __builtin_bit_cast(bf16x8_t, S.bfr[SLOT][nt * 2 + (p == 1 ? 1 : 0)]),
+                                                               S.acc[m][nt], 0, 0, 0);
+#endif
+  __builtin_amdgcn_sched_barrier(0);
+  {   // DMA of the sub-phase three ahead, spread over this sub-phase's steps (its slot was freed at the last barrier)
+    constexpr int tsp = (sp + 3) & 7;
+    constexpr int N = p4_cls_ni(tsp >> 1);
+#ifdef P4_DMA_SAME   // ablation build: every DMA reads the item's first lines
+    p4_dma_range<G, tsp, t * N / L, (t + 1) * N / L>(S, S.x0);
+#else
+    p4_dma_range<G, tsp, t * N / L, (t + 1) * N / L>(S, sp + 3 >= 8 ? xnext : xcur);
+#endif
+  }
+  p4_load_b<G, (J + PF) % P4_NSTEP, SLOT>(S);
+  __builtin_amdgcn_sched_barrier(0);
+}
+template <class G, int... Js>
+__device__ __forceinline__ void p4_steps(P4Wave<G::PF>& S, const char* xcur, const char* xnext, std::integer_sequence<int, Js...>) {
+  (p4_step<G, Js>(S, xcur, xnext), ...);
+}
+
+template <class G>
+__global__ __launch_bounds__(256, 1) void pconv4_fwd_kernel(const PConv4Args a) {
+  constexpr int PF = G::PF;
+  extern __shared__ __attribute__((aligned(16))) unsigned char p_smem[];
+  // blocks of one group on the same XCDs (workgroups are dealt round-robin to the 8 XCDs): an XCD's L2 then holds the
+  // weights of one group instead of all of them
+  int z, bx;
+  {
+    const int id = blockIdx.x;
+    if (a.xcd_map) {
+      const int xcd = id & 7, per = 8 / a.ngroups;
+      z = xcd % a.ngroups;
+      bx = (id >> 3) * per + xcd / a.ngroups;
+    } else {
+      z = id / a.gx; bx = id - z * a.gx;
+    }
+  }
+  if (bx >= a.nitems) return;                               // block-uniform, before any barrier
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+
+  P4Wave<PF> S;
+  S.smem = p_smem; S.wid = wid; S.x0 = reinterpret_cast<const char*>(a.x[z]);
+  S.wq_base = reinterpret_cast<const char*>(a.wq[z]);
+  S.wq_voff = (uint32_t)(wid * 4096 + lane * 16);
+  {   // fragment addresses: row m = 32 tile + r of the item -> (image, oy, ox) -> record of the class's grid
+    const uint32_t lbase = (uint32_t)(size_t)(pconv_lptr_t)p_smem;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int row = min(m * 32 + r, 97);
+      const int img = row / 49, p = row - img * 49, oy = p / 7, ox = p - oy * 7;
+#pragma unroll
+      for (int cl = 0; cl < 4; ++cl)
+        S.abase[cl][m] = lbase + p4_slot_off((cl & 1) * 2) + (img * p4_cls_np(cl) + oy * p4_cls_w(cl) + ox) * G::REC + h * 16;
+    }
+  }
+  {   // DMA sources: chunk g = 64 (4 i + wid) + lane of a slot = chunk g % 17 of record g / 17 (chunk 16 is padding)
+#pragma unroll
+    for (int cl = 0; cl < 4; ++cl)
+#pragma unroll
+      for (int i = 0; i < p4_cls_ni(cl); ++i) {
+        const int g = 64 * (4 * i + wid) + lane;
+        int rec = g / 17, c = g - rec * 17;
+        if (c == 16) c = 0;
+        if (rec >= 2 * p4_cls_np(cl)) rec = 0;
+        const int img = rec / p4_cls_np(cl), rem = rec - img * p4_cls_np(cl);
+        const int cy = rem / p4_cls_w(cl), cx = rem - cy * p4_cls_w(cl);
+        const int iy = 2 * cy + (cl >> 1), ix = 2 * cx + (cl & 1);
+        S.doff[p4_cls_d0(cl) + i] = (uint32_t)(((img * 225 + iy * 15 + ix) * 512) + (c >> 3) * 256 + (c & 7) * 16);
+      }
+  }
+  const int chq = lane & 7;
+  float bs[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) bs[j] = a.bias[z][wid * 64 + chq * 8 + j];
+  unsigned short* const out = a.y[z];
+  unsigned char* const mk = a.rmask[z];
+  const char* const xz = reinterpret_cast<const char*>(a.x[z]);
+
+  // ---- prologue: the first three sub-phases of the first item and the first PF steps of weights
+  {
+    const char* x0 = xz + (size_t)bx * 2 * G::B_IMG;
+    p4_dma_range<G, 0, 0, p4_cls_ni(0)>(S, x0);
+    p4_dma_range<G, 1, 0, p4_cls_ni(0)>(S, x0);
+    p4_dma_range<G, 2, 0, p4_cls_ni(1)>(S, x0);
+  }
+  p4_load_b_first<G>(S, std::make_integer_sequence<int, PF>{});
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  p4_load_a<G, 0, 0>(S);
+
+  for (int item = bx; item < a.nitems; item += a.gx) {
+    const int nitem = item + a.gx < a.nitems ? item + a.gx : item;          // behind the last item: the same pixels again, into idle slots
+    const char* xcur = xz + (size_t)item * 2 * G::B_IMG;
+    const char* xnext = xz + (size_t)nitem * 2 * G::B_IMG;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) S.acc[m][nt][q] = 0.f;
+    p4_steps<G>(S, xcur, xnext, std::make_integer_sequence<int, P4_NSTEP>{});
+
+    // ---- output: 16 rows x 64 channels at a time through the wave's own fp32 tile; a lane finishes 8 channels of a row
+    float* const stg = reinterpret_cast<float*>(p_smem + G::STAGE + wid * G::STAGE_W);
+    const uint32_t stg_l = (uint32_t)(size_t)(pconv_lptr_t)stg;
+#ifdef P4_NO_EPI     // ablation build: no output rounds; the accumulators stay alive through a sum that is (never) stored
+    constexpr int NROUND = 0;
+    {
+      float ssum = 0.f;
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) ssum += S.acc[m][nt][q];
+      if (ssum == 12345.678f) out[lane] = 1;
+    }
+#else
+    constexpr int NROUND = 7;
+#endif
+#pragma unroll
+    for (int hf8 = 0; hf8 < NROUND; ++hf8) {     // (M tile, half): rows 16 hf8 .. + 15; tile 3 has rows 96, 97 only
+      const int m = hf8 >> 1, hf = hf8 & 1;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the reads of the previous round are done
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int qq = 0; qq < 8; ++qq)
+          stg[((qq & 3) + 8 * (qq >> 2) + 4 * h) * 68 + nt * 32 + r] = S.acc[m][nt][hf * 8 + qq];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        int rl = (lane >> 3) + 8 * u;
+        if (hf8 == 6) rl = min(rl, 1);             // every lane stores (a count the waits rely on): the same row again
+        const int row = hf8 * 16 + rl;
+        u32x4_t c0, c1;
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(c0), "=&v"(c1) : "v"(stg_l + (uint32_t)(rl * 272 + chq * 32)) : "memory");
+        float v[8] = {__uint_as_float(c0[0]), __uint_as_float(c0[1]), __uint_as_float(c0[2]), __uint_as_float(c0[3]),
+                      __uint_as_float(c1[0]), __uint_as_float(c1[1]), __uint_as_float(c1[2]), __uint_as_float(c1[3])};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          v[j] = fmaf(v[j], 1.0f, bs[j]);
+          if (a.relu) v[j] = fmaxf(v[j], 0.f);
+        }
+        u32x4_t hi, lo;
+        uint32_t hh, ll;
+        split_pair(v[0], v[1], hh, ll); hi[0] = hh; lo[0] = ll;
+        split_pair(v[2], v[3], hh, ll); hi[1] = hh; lo[1] = ll;
+        split_pair(v[4], v[5], hh, ll); hi[2] = hh; lo[2] = ll;
+        split_pair(v[6], v[7], hh, ll); hi[3] = hh; lo[3] = ll;
+        const size_t pix = (size_t)item * 98 + row;
+        unsigned short* dst = out + pix * 512 + wid * 64 + chq * 8;
+        *reinterpret_cast<u32x4_t*>(dst) = hi;
+        *reinterpret_cast<u32x4_t*>(dst + 256) = lo;
+        if (mk != nullptr) {
+          uint32_t bits = 0;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            bits |= (hi[j] & 0x7fffu) ? (1u << (2 * j)) : 0u;
+            bits |= (hi[j] & 0x7fff0000u) ? (2u << (2 * j)) : 0u;
+          }
+          mk[pix * 32 + wid * 8 + chq] = (unsigned char)bits;
+        }
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // nothing may still be landing when the block's LDS is handed on
+}
+
+static bool pconv4_fits(int B, int IH, int IW, int C, int KH, int KW, int stride, int F) {
+  return KH == 3 && KW == 3 && stride == 2 && IH == 15 && IW == 15 && C == 128 && F == 256 && B >= 2 && B % 2 == 0;
+}
+
+template <class G>
+static int pconv4_fwd_launch(PConv4Args a, int ngroups, hipStream_t st, const char* name) {
+  static bool opted[64] = {};
+  static int ncu[64] = {};
+  int dev = 0;
+  SERL_CHECK_HIP(hipGetDevice(&dev), name);
+  SERL_CHECK_ARG(dev >= 0 && dev < 64, "%s: device ordinal %d out of range", name, dev);
+  if (!opted[dev]) {
+    SERL_CHECK_HIP(hipFuncSetAttribute((const void*)pconv4_fwd_kernel<G>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS), name);
+    SERL_CHECK_HIP(hipDeviceGetAttribute(&ncu[dev], hipDeviceAttributeMultiprocessorCount, dev), name);
+    opted[dev] = true;
+  }
+  a.nitems = a.B / 2;
+  a.ngroups = ngroups;
+  int gx = pconv_cus(ncu[dev]) / ngroups;
+  if (gx < 1) gx = 1;
+  if (gx > a.nitems) gx = a.nitems;
+  gx = cdiv(a.nitems, cdiv(a.nitems, gx));
+  a.xcd_map = 0;
+  if (8 % ngroups == 0) {          // a whole number of XCDs per group: round the grid up to it (surplus blocks return at once)
+    const int per = 8 / ngroups;
+    gx = cdiv(gx, per) * per;
+    a.xcd_map = 1;
+  }
+  a.gx = gx;
+  hipLaunchKernelGGL((pconv4_fwd_kernel<G>), dim3(gx * ngroups), dim3(256), G::LDS, st, a);
+  SERL_CHECK_LAUNCH(name);
+  return SERL_OK;
+}

@@ -229,7 +229,7 @@ def test_convs_fwd_dgrad_wgrad(dev, case):
 
 
 @pytest.mark.parametrize("case", [(3, 63, 63, 32, 64), (2, 64, 63, 32, 64), (3, 31, 31, 64, 128), (2, 29, 32, 64, 128),
-                                  (1, 9, 11, 32, 64), (6, 15, 15, 128, 256), (1, 16, 13, 128, 256), (1, 7, 7, 64, 136),
+                                  (1, 9, 11, 32, 64), (5, 15, 15, 128, 256), (1, 16, 13, 128, 256), (1, 7, 7, 64, 136),
                                   (40, 31, 31, 64, 128), (30, 13, 9, 64, 128),
                                   # C=32 -> 64 with >= 4 items per persistent block (85 blocks per group): the double-
                                   # buffered patch, the counted vmcnt waits with the previous item's stores in flight and
@@ -300,6 +300,69 @@ def test_patch_conv_bit_identical_to_im2col(dev, case):
             a_, b_ = a_.cpu().numpy(), b_.cpu().numpy()
             assert np.isfinite(b_).all()
             np.testing.assert_allclose(b_, a_, rtol=0, atol=2e-5 * max(1.0, float(np.abs(a_).max())))
+
+
+@pytest.mark.parametrize("case", [(2, 3), (6, 3), (44, 2), (260, 4), (256, 1)])
+def test_last_layer_forward_matches_im2col(dev, case):
+    """pconv4_fwd_kernel (csrc/pconv4.h: the 15 x 15 x 128 -> 7 x 7 x 256 layer, K loop ordered by the parity class of the
+    input pixel) against the im2col kernel (mode 8): the same bf16_3x products summed in another order -> equal to 2e-6 of
+    the output scale or one step of the 16-bit S-format mantissa, not bit for bit; the ReLU byte masks describe the kernel's own output; a NULL mask entry is not
+    written; identical when repeated.  One item per block, several items per block (260 images in 4 groups: 3 items), the
+    XCD-grouped block order (groups dividing 8) and the plain one (3 groups)."""
+    ops = _ops()
+    B, G = case
+    IH = IW = 15; Cin, F, K, S = 128, 256, 3, 2
+    OH = OW = 7
+    rng = np.random.default_rng(31)
+    st = ops.current_stream()
+    wb = ops.convs_weight_bytes(False, K, K, Cin, F)
+    assert wb == 2 * 4 * 9 * Cin * F          # S-format image + the fragment-ordered image
+    xs, wfs, bs, keep = [], [], [], []
+    for g in range(G):
+        x = np.maximum(rng.standard_normal((B, IH, IW, Cin)).astype(np.float32), 0)
+        buf, _ = _to_s(ops, dv(x, dev), B * IH * IW, Cin, st)
+        xs.append(buf)
+        keep.append(dv((rng.standard_normal((K, K, Cin, F)) * 0.05).astype(np.float32), dev))
+        wfs.append(torch.full((wb // 2,), -1, dtype=torch.int16, device=dev))
+        bs.append(dv((rng.standard_normal(F) * 0.1).astype(np.float32), dev))
+    ops.convs_prep_weights([t.data_ptr() for t in keep], [t.data_ptr() for t in wfs], None, False, K, K, Cin, F, st)
+    out = {}
+    try:
+        for mode in (8, 1, "again"):
+            ops.convs_set_patch_kernels(1 if mode == "again" else mode)
+            ys = [torch.full((B * OH * OW * F * 2,), -1, dtype=torch.int16, device=dev) for _ in range(G)]
+            rm = [torch.full((B * OH * OW * F // 8,), 0xAA, dtype=torch.uint8, device=dev) for _ in range(G)]
+            ops.convs_fwd([t.data_ptr() for t in xs], [t.data_ptr() for t in wfs], [t.data_ptr() for t in bs],
+                          [t.data_ptr() for t in ys], False, B, IH, IW, Cin, K, K, S, F, True, st,
+                          rmasks=[t.data_ptr() if g != 1 else 0 for g, t in enumerate(rm)])
+            torch.cuda.synchronize()
+            out[mode] = (ys, rm)
+    finally:
+        ops.convs_set_patch_kernels(1)
+    for g in range(G):
+        ref = _from_s(ops, out[8][0][g], B * OH * OW, F, st)
+        got = _from_s(ops, out[1][0][g], B * OH * OW, F, st)
+        assert np.isfinite(got).all()
+        # (the S format keeps 16 mantissa bits: a sum that differs in its last fp32 bits may round to the neighbouring value)
+        np.testing.assert_allclose(got, ref, rtol=2.0 ** -14, atol=2e-6 * float(np.abs(ref).max()))
+        assert torch.equal(out[1][0][g], out["again"][0][g]) and torch.equal(out[1][1][g], out["again"][1][g])
+        if g == 1:
+            assert bool((out[1][1][g] == 0xAA).all()), "a NULL mask entry must not be written"
+        else:
+            hi = out[1][0][g].view(B * OH * OW, 2, F)[:, 0, :].cpu().numpy().view(np.uint16)
+            want = np.packbits((hi & 0x7fff) != 0, axis=1, bitorder="little").reshape(-1)
+            assert np.array_equal(out[1][1][g].cpu().numpy(), want), "ReLU byte mask does not describe the output"
+    # and against float64 on the first images
+    nb = min(B, 2)
+    x0 = _from_s(ops, xs[0], B * IH * IW, Cin, st).reshape(B, IH, IW, Cin)[:nb].astype(np.float64)
+    w0 = keep[0].cpu().numpy().astype(np.float64)
+    ref = np.zeros((nb, OH, OW, F))
+    for ky in range(K):
+        for kx in range(K):
+            ref += np.einsum("bhwc,cf->bhwf", x0[:, ky:ky + 2 * OH - 1:2, kx:kx + 2 * OW - 1:2, :], w0[ky, kx])
+    ref = np.maximum(ref + bs[0].cpu().numpy().astype(np.float64), 0)
+    got = _from_s(ops, out[1][0][0], B * OH * OW, F, st).reshape(B, OH, OW, F)[:nb]
+    np.testing.assert_allclose(got, ref, rtol=0, atol=2e-5 * float(np.abs(ref).max()))
 
 
 @pytest.mark.parametrize("masked", [True, False])
