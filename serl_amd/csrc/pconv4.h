@@ -69,7 +69,7 @@ struct P4Cfg {
   static constexpr int STAGE_W = 16 * 272;           // wave-private output tile: 16 rows x (64 + 4) floats
   static constexpr int LDS = STAGE + 4 * STAGE_W;
   static constexpr int NST = 28;                     // output stores per wave and item without the masks
-  static_assert(P4_NSTEP % PF == 0 && PF >= 2 && PF <= 8, "weight ring");
+  static_assert(P4_NSTEP % PF == 0 && PF >= 3 && PF <= 8, "weight ring");
   static_assert(LDS <= 160 * 1024, "LDS");
   static_assert(p4_cls_ni(0) * 4096 <= SLOT1 - SLOT0 && p4_cls_ni(1) * 4096 <= SLOT3 - SLOT2 && p4_cls_ni(1) * 4096 <= STAGE - SLOT3, "slots");
 };
@@ -91,20 +91,26 @@ struct P4Wave {
 
 #define P4_LD(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(dst) : "v"(addr), "n"(imm) : "memory")
 
-// A fragments of step J into register set SET
-template <class G, int J, int SET>
-__device__ __forceinline__ void p4_load_a(P4Wave<G::PF>& S) {
+// A fragments of step J into register set SET: all eight reads, or read I (M tile I / 2, plane I % 2) alone
+template <class G, int J>
+constexpr int p4_a_imm() {
   constexpr int sp = p4_sp_of(J), cl = sp >> 1, half = sp & 1, t = J - p4_sp_start(sp);
   constexpr int tp = t >> 2, s = t & 3;
   constexpr int ntx = (cl & 1) ? 1 : 2;
   constexpr int dy = tp / ntx, dx = tp % ntx;
   constexpr int slot0 = (cl & 1) * 2;
-  constexpr int imm = half * (p4_slot_off(slot0 + 1) - p4_slot_off(slot0)) + (dy * p4_cls_w(cl) + dx) * G::REC + s * 32;
-#pragma unroll
-  for (int m = 0; m < 4; ++m) {
-    P4_LD(S.afr[SET][m][0], S.abase[cl][m], imm);
-    P4_LD(S.afr[SET][m][1], S.abase[cl][m], imm + 128);
-  }
+  return half * (p4_slot_off(slot0 + 1) - p4_slot_off(slot0)) + (dy * p4_cls_w(cl) + dx) * G::REC + s * 32;
+}
+template <class G, int J, int SET, int I>
+__device__ __forceinline__ void p4_load_a1(P4Wave<G::PF>& S) {
+  constexpr int cl = p4_sp_of(J) >> 1;
+  constexpr int imm = p4_a_imm<G, J>() + (I & 1) * 128;
+  P4_LD(S.afr[SET][I >> 1][I & 1], S.abase[cl][I >> 1], imm);
+}
+template <class G, int J, int SET>
+__device__ __forceinline__ void p4_load_a(P4Wave<G::PF>& S) {
+  p4_load_a1<G, J, SET, 0>(S); p4_load_a1<G, J, SET, 1>(S); p4_load_a1<G, J, SET, 2>(S); p4_load_a1<G, J, SET, 3>(S);
+  p4_load_a1<G, J, SET, 4>(S); p4_load_a1<G, J, SET, 5>(S); p4_load_a1<G, J, SET, 6>(S); p4_load_a1<G, J, SET, 7>(S);
 }
 
 // DMA instruction I (of this wave) of sub-phase TSP of the item whose first image starts at `ximg`
@@ -144,24 +150,54 @@ __device__ __forceinline__ void p4_load_b(P4Wave<G::PF>& S) {
 }
 
 // vector-memory instructions a wave issues in k16 step i (0 .. 71): the DMA share of the sub-phase three ahead, then 4
-// weight loads
+// weight loads (of step i + PF - 1)
 __host__ __device__ constexpr int p4_nd(int i) {
   const int sp = p4_sp_of(i), t = i - p4_sp_start(sp), L = p4_sp_len(sp), N = p4_cls_ni(((sp + 3) & 7) >> 1);
   return (t + 1) * N / L - t * N / L;
 }
-// ... issued after the weight loads of step T (T - PF .. : absolute step, negative = previous item) and before the waits
-// of step J; the output stores of the previous item (at least NST of them) lie between its step 71 and step 0.  vmcnt
-// retires in order, so "at most this many outstanding" = the fragments of step T have arrived (fewer is stricter).
+// ... issued after the weight loads of step T (requested in step T - PF + 1, into the ring slot the step before freed;
+// absolute steps, negative = previous item) and before the waits of step J; the output stores of the previous item (at
+// least NST of them) lie between its step 71 and step 0.  vmcnt retires in order, so "at most this many outstanding" =
+// the fragments of step T have arrived (fewer is stricter).
 template <int PF, int NST>
 __host__ __device__ constexpr int p4_younger(int T, int J) {
-  int n = T - PF < 0 ? NST : 0;
-  for (int a = T - PF + 1; a < J; ++a) n += p4_nd((a + P4_NSTEP) % P4_NSTEP) + 4;
+  int n = T - PF + 1 < 0 ? NST : 0;
+  for (int a = T - PF + 2; a < J; ++a) n += p4_nd((a + P4_NSTEP) % P4_NSTEP) + 4;
   return n > 63 ? 63 : n;
 }
 
 template <class G, int... Js>
 __device__ __forceinline__ void p4_load_b_first(P4Wave<G::PF>& S, std::integer_sequence<int, Js...>) {
   (p4_load_b<G, Js, Js>(S), ...);
+}
+
+template <class G, int J, int I>
+__device__ __forceinline__ void p4_mfma(P4Wave<G::PF>& S, const char* xcur, const char* xnext) {
+  constexpr int PF = G::PF;
+  constexpr int sp = p4_sp_of(J), t = J - p4_sp_start(sp), L = p4_sp_len(sp);
+  constexpr int JN = (J + 1) % P4_NSTEP, SET = J & 1, SLOT = J % PF;
+  constexpr int p = I / 8, m = (I % 8) / 2, nt = I % 2;
+#ifndef P4_NO_MMA   // (ablation build)
+  S.acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, S.afr[SET][m][p == 0 ? 1 : 0]),
+                                                         __builtin_bit_cast(bf16x8_t, S.bfr[SLOT][nt * 2 + (p == 1 ? 1 : 0)]),
+                                                         S.acc[m][nt], 0, 0, 0);
+#endif
+  if constexpr (I % 2 == 0 && I < 16) p4_load_a1<G, JN, SET ^ 1, I / 2>(S);
+  if constexpr (I == 17) {   // DMA of the sub-phase three ahead, spread over this sub-phase's steps (its slot was freed at the last barrier)
+    constexpr int tsp = (sp + 3) & 7;
+    constexpr int N = p4_cls_ni(tsp >> 1);
+#ifdef P4_DMA_SAME   // ablation build: every DMA reads the item's first lines
+    p4_dma_range<G, tsp, t * N / L, (t + 1) * N / L>(S, S.x0);
+#else
+    p4_dma_range<G, tsp, t * N / L, (t + 1) * N / L>(S, sp + 3 >= 8 ? xnext : xcur);
+#endif
+  }
+  if constexpr (I == 19) p4_load_b<G, (J + PF - 1) % P4_NSTEP, (J + PF - 1) % PF>(S);
+  __builtin_amdgcn_sched_barrier(0);
+}
+template <class G, int J, int... Is>
+__device__ __forceinline__ void p4_mfmas(P4Wave<G::PF>& S, const char* xcur, const char* xnext, std::integer_sequence<int, Is...>) {
+  (p4_mfma<G, J, Is>(S, xcur, xnext), ...);
 }
 
 template <class G, int J>
@@ -189,31 +225,10 @@ __device__ __forceinline__ void p4_step(P4Wave<G::PF>& S, const char* xcur, cons
     __builtin_amdgcn_s_barrier();
   }
   __builtin_amdgcn_sched_barrier(0);
-  p4_load_a<G, JN, SET ^ 1>(S);
-  __builtin_amdgcn_sched_barrier(0);
-#ifndef P4_NO_MMA   // (ablation build)
-#pragma unroll
-  for (int p = 0; p < 3; ++p)
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
-        S.acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, S.afr[SET][m][p == 0 ? 1 : 0]),
-                                                               __builtin_bit_cast(bf16x8_t, S.bfr[SLOT][nt * 2 + (p == 1 ? 1 : 0)]),
-                                                               S.acc[m][nt], 0, 0, 0);
-#endif
-  __builtin_amdgcn_sched_barrier(0);
-  {   // DMA of the sub-phase three ahead, spread over this sub-phase's steps (its slot was freed at the last barrier)
-    constexpr int tsp = (sp + 3) & 7;
-    constexpr int N = p4_cls_ni(tsp >> 1);
-#ifdef P4_DMA_SAME   // ablation build: every DMA reads the item's first lines
-    p4_dma_range<G, tsp, t * N / L, (t + 1) * N / L>(S, S.x0);
-#else
-    p4_dma_range<G, tsp, t * N / L, (t + 1) * N / L>(S, sp + 3 >= 8 ? xnext : xcur);
-#endif
-  }
-  p4_load_b<G, (J + PF) % P4_NSTEP, SLOT>(S);
-  __builtin_amdgcn_sched_barrier(0);
+  // One wave per SIMD: whatever is not an MFMA is issued in the shadow of one (32 cycles each) -- the next step's A
+  // fragments behind the first 16 MFMAs, this step's DMA share and the weight fragments of step J + PF - 1 (into the ring
+  // slot step J - 1 used) behind the next ones -- instead of in a block between the steps with the matrix pipe idle.
+  p4_mfmas<G, J>(S, xcur, xnext, std::make_integer_sequence<int, 24>{});
 }
 template <class G, int... Js>
 __device__ __forceinline__ void p4_steps(P4Wave<G::PF>& S, const char* xcur, const char* xnext, std::integer_sequence<int, Js...>) {
@@ -279,14 +294,14 @@ __global__ __launch_bounds__(256, 1) void pconv4_fwd_kernel(const PConv4Args a) 
   unsigned char* const mk = a.rmask[z];
   const char* const xz = reinterpret_cast<const char*>(a.x[z]);
 
-  // ---- prologue: the first three sub-phases of the first item and the first PF steps of weights
+  // ---- prologue: the first three sub-phases of the first item and the first PF - 1 steps of weights
   {
     const char* x0 = xz + (size_t)bx * 2 * G::B_IMG;
     p4_dma_range<G, 0, 0, p4_cls_ni(0)>(S, x0);
     p4_dma_range<G, 1, 0, p4_cls_ni(0)>(S, x0);
     p4_dma_range<G, 2, 0, p4_cls_ni(1)>(S, x0);
   }
-  p4_load_b_first<G>(S, std::make_integer_sequence<int, PF>{});
+  p4_load_b_first<G>(S, std::make_integer_sequence<int, PF - 1>{});
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   p4_load_a<G, 0, 0>(S);

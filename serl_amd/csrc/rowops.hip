@@ -276,46 +276,64 @@ struct LnBwdSegArgs {
   float* dz[LN_MAXSEG]; float* g[LN_MAXSEG]; int N[LN_MAXSEG];
   int nslab; long long dy_ss; int R, act;
 };
+// MW = 64-column chunks a lane holds.  Every load is unconditional (columns past N read column N - 1 and contribute
+// nothing) and the slab loop is the OUTER one, so a lane has MW x 4 independent loads in flight instead of one chain of
+// nslab dependent round trips per chunk (39 -> 12 us at 256 rows x (512 + 64) columns x 8 slabs); the sum over the slabs
+// keeps its order.
+template <int MW>
+__device__ __forceinline__ void ln_act_bwd_seg_body(const LnBwdSegArgs& a, int sg, int row, int lane) {
+  const int N = a.N[sg];
+  const float* gamma = a.gamma[sg];
+  const float* src = a.dy[sg] + (long long)row * a.lddy[sg];
+  int nn[MW];
+  float d[MW], yv[MW], xh[MW], gm[MW];
+#pragma unroll
+  for (int i = 0; i < MW; ++i) {
+    nn[i] = min(lane + 64 * i, N - 1);
+    d[i] = 0.f;
+    yv[i] = a.y[sg][(long long)row * a.ldy[sg] + nn[i]];
+    xh[i] = a.xhat[sg][(long long)row * N + nn[i]];
+    gm[i] = gamma[nn[i]];
+  }
+#pragma unroll 4
+  for (int k = 0; k < a.nslab; ++k) {
+    const float* sk = src + k * a.dy_ss;
+#pragma unroll
+    for (int i = 0; i < MW; ++i) d[i] += sk[nn[i]];
+  }
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < MW; ++i) {
+    float dact = 1.f;
+    if (a.act == ACT_RELU) dact = yv[i] > 0.f ? 1.f : 0.f;
+    else if (a.act == ACT_TANH) dact = 1.f - yv[i] * yv[i];
+    else if (a.act == ACT_LEAKY) dact = yv[i] > 0.f ? 1.f : 0.01f;
+    d[i] = d[i] * dact;                       // g
+    if (lane + 64 * i < N) {
+      const float dxh = d[i] * gm[i];
+      s1 += dxh;
+      s2 += dxh * xh[i];
+    }
+  }
+  const float m1 = wave_sum(s1) / (float)N, m2 = wave_sum(s2) / (float)N, rs = a.rstd[sg][row];
+#pragma unroll
+  for (int i = 0; i < MW; ++i) {
+    const int n = lane + 64 * i;
+    if (n < N) {
+      a.g[sg][(long long)row * N + n] = d[i];
+      a.dz[sg][(long long)row * N + n] = rs * (d[i] * gm[i] - m1 - xh[i] * m2);
+    }
+  }
+}
 __global__ __launch_bounds__(256) void ln_act_bwd_seg_kernel(const LnBwdSegArgs a) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= a.R) return;
   const int sg = blockIdx.y;
-  const int N = a.N[sg];
-  const float* gamma = a.gamma[sg];
-  float gv[MAXW], xh[MAXW];
-  float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-  for (int i = 0; i < MAXW; ++i) {
-    const int n = lane + 64 * i;
-    float g = 0.f, x = 0.f;
-    if (n < N) {
-      const float* src = a.dy[sg] + (long long)row * a.lddy[sg] + n;
-      float d = 0.f;
-#pragma unroll 8
-      for (int k = 0; k < a.nslab; ++k) d += src[k * a.dy_ss];
-      const float yv = a.y[sg][(long long)row * a.ldy[sg] + n];
-      float dact = 1.f;
-      if (a.act == ACT_RELU) dact = yv > 0.f ? 1.f : 0.f;
-      else if (a.act == ACT_TANH) dact = 1.f - yv * yv;
-      else if (a.act == ACT_LEAKY) dact = yv > 0.f ? 1.f : 0.01f;
-      g = d * dact;
-      x = a.xhat[sg][(long long)row * N + n];
-      const float dxh = g * gamma[n];
-      s1 += dxh;
-      s2 += dxh * x;
-    }
-    gv[i] = g;
-    xh[i] = x;
-  }
-  const float m1 = wave_sum(s1) / (float)N, m2 = wave_sum(s2) / (float)N, rs = a.rstd[sg][row];
-#pragma unroll
-  for (int i = 0; i < MAXW; ++i) {
-    const int n = lane + 64 * i;
-    if (n < N) {
-      a.g[sg][(long long)row * N + n] = gv[i];
-      a.dz[sg][(long long)row * N + n] = rs * (gv[i] * gamma[n] - m1 - xh[i] * m2);
-    }
-  }
+  const int N = a.N[sg];              // block-uniform
+  if (N <= 64) ln_act_bwd_seg_body<1>(a, sg, row, lane);
+  else if (N <= 256) ln_act_bwd_seg_body<4>(a, sg, row, lane);
+  else if (N <= 512) ln_act_bwd_seg_body<8>(a, sg, row, lane);
+  else ln_act_bwd_seg_body<MAXW>(a, sg, row, lane);
 }
 extern "C" int serl_ln_act_bwd_seg(int nseg, const float* const* dy, const int* lddy, int dy_nslab,
                                    long long dy_slab_stride, const float* const* y, const int* ldy,
