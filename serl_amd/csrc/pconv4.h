@@ -87,6 +87,7 @@ struct P4Wave {
   unsigned char* smem;
   int wid;
   const char* x0;
+  uint32_t nmask;              // offset mask of the DMA for the NEXT item: all ones, or (behind the last item) the zero page's 8 KB
 };
 
 #define P4_LD(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(dst) : "v"(addr), "n"(imm) : "memory")
@@ -115,18 +116,18 @@ __device__ __forceinline__ void p4_load_a(P4Wave<G::PF>& S) {
 
 // DMA instruction I (of this wave) of sub-phase TSP of the item whose first image starts at `ximg`
 template <class G, int TSP, int I>
-__device__ __forceinline__ void p4_dma(const P4Wave<G::PF>& S, const char* ximg) {
+__device__ __forceinline__ void p4_dma(const P4Wave<G::PF>& S, const char* ximg, uint32_t omask = 0xffffffffu) {
   constexpr int tcl = TSP >> 1;
-  uint32_t o = S.doff[p4_cls_d0(tcl) + I];
+  uint32_t o = S.doff[p4_cls_d0(tcl) + I] & omask;
   asm volatile("" : "+v"(o));                 // (opaque: no hoisted 64-bit addresses)
   const char* g = ximg + (TSP & 1) * 128 + (size_t)o;
   __builtin_amdgcn_global_load_lds((pconv_gptr_t)g, (pconv_lptr_t)(S.smem + p4_slot_off(TSP & 3) + (I * 4 + S.wid) * 1024), 16, 0, 0);
 }
 template <class G, int TSP, int I0, int I1>
-__device__ __forceinline__ void p4_dma_range(const P4Wave<G::PF>& S, const char* ximg) {
+__device__ __forceinline__ void p4_dma_range(const P4Wave<G::PF>& S, const char* ximg, uint32_t omask = 0xffffffffu) {
   if constexpr (I0 < I1) {
-    p4_dma<G, TSP, I0>(S, ximg);
-    p4_dma_range<G, TSP, I0 + 1, I1>(S, ximg);
+    p4_dma<G, TSP, I0>(S, ximg, omask);
+    p4_dma_range<G, TSP, I0 + 1, I1>(S, ximg, omask);
   }
 }
 
@@ -189,7 +190,8 @@ __device__ __forceinline__ void p4_mfma(P4Wave<G::PF>& S, const char* xcur, cons
 #ifdef P4_DMA_SAME   // ablation build: every DMA reads the item's first lines
     p4_dma_range<G, tsp, t * N / L, (t + 1) * N / L>(S, S.x0);
 #else
-    p4_dma_range<G, tsp, t * N / L, (t + 1) * N / L>(S, sp + 3 >= 8 ? xnext : xcur);
+    if constexpr (sp + 3 >= 8) p4_dma_range<G, tsp, t * N / L, (t + 1) * N / L>(S, xnext, S.nmask);
+    else p4_dma_range<G, tsp, t * N / L, (t + 1) * N / L>(S, xcur);
 #endif
   }
   if constexpr (I == 19) p4_load_b<G, (J + PF - 1) % P4_NSTEP, (J + PF - 1) % PF>(S);
@@ -307,9 +309,12 @@ __global__ __launch_bounds__(256, 1) void pconv4_fwd_kernel(const PConv4Args a) 
   p4_load_a<G, 0, 0>(S);
 
   for (int item = bx; item < a.nitems; item += a.gx) {
-    const int nitem = item + a.gx < a.nitems ? item + a.gx : item;          // behind the last item: the same pixels again, into idle slots
+    // behind the last item the DMA instructions of "the next item" are still issued (the waits count them): 8 KB of zeros
+    // into idle slots
+    const bool more = item + a.gx < a.nitems;
     const char* xcur = xz + (size_t)item * 2 * G::B_IMG;
-    const char* xnext = xz + (size_t)nitem * 2 * G::B_IMG;
+    const char* xnext = more ? xz + (size_t)(item + a.gx) * 2 * G::B_IMG : reinterpret_cast<const char*>(g_zero_page);
+    S.nmask = more ? 0xffffffffu : 0x1e00u;        // (+ 128 for the second half + 384 of a chunk offset stay inside the page)
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll

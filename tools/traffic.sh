@@ -1,19 +1,21 @@
 #!/bin/bash
-# usage: tools/traffic.sh <out.json>  -- HBM-side traffic of every conv launch of the bench workload:
+# usage: [TRAFFIC_OPS="conv4_fwd@4 ..."] tools/traffic.sh <out.json>  -- HBM-side traffic of every conv launch of the bench workload:
 # rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs (MI355X_MICROARCH.md, HBM section), one
 # launch configuration per run (tools/bench_conv.py, BENCH_ONLY), averaged over the dispatches of the run.
 OUT=$1
 # <layer>_<op>@<groups>: forward launches carry 4 groups (target + critic passes) or 2 (actor run-ahead pass)
 # (since round 2 the driver launches: conv1 fwd with 2 groups (the differentiated pass), layers 1+2 of the other passes fused
 #  (fwd12, 2 groups per launch), conv2 fwd with 2 groups, conv3/conv4 fwd with 4 and 2 groups)
-OPS="conv1_fwd@2 conv1_fwd12@2 conv1_wgrad@2 conv2_fwd@4 conv2_fwd@2 conv2_wgrad@2 conv2_dgrad@2 conv3_fwd@4 conv3_fwd@2 conv3_wgrad@2 conv3_dgrad@2 conv4_fwd@4 conv4_fwd@2 conv4_wgrad@2 conv4_dgrad@2"
+OPS=${TRAFFIC_OPS:-"conv1_fwd@2 conv1_fwd12@2 conv1_wgrad@2 conv2_fwd@4 conv2_fwd@2 conv2_wgrad@2 conv2_dgrad@2 conv2_dgw1@2 conv3_fwd@4 conv3_fwd@2 conv3_wgrad@2 conv3_dgrad@2 conv4_fwd@4 conv4_fwd@2 conv4_wgrad@2 conv4_dgrad@2"}
 CMD="mkdir -p gpurun_out/traffic && cd /tmp && export TMPDIR=/tmp && export BENCH_N=2"
 for OPG in $OPS; do
   OP=${OPG%@*}; G=${OPG#*@}
   SCRIPT=bench_conv.py
   if [ "$OP" = conv1_fwd12 ]; then SCRIPT=bench_fused12.py; fi
+  ONLY="${OP/_/ }"
+  if [ "$OP" = conv2_dgw1 ]; then ONLY=dgw1; fi      # conv2's data gradient + conv1's weight gradient in one launch
   for P in FETCH_SIZE WRITE_SIZE; do
-    CMD="$CMD && BENCH_G=$G BENCH_FWD_G=$G BENCH_ONLY='${OP/_/ }' timeout -s KILL 120 rocprofv3 --pmc $P --output-format csv -d \$GRAFT_REPO_ROOT/gpurun_out/traffic/${OP}_g${G}_$P -- python3 \$GRAFT_REPO_ROOT/tools/$SCRIPT > \$GRAFT_REPO_ROOT/gpurun_out/traffic/${OP}_g${G}_$P.out 2>&1"
+    CMD="$CMD && BENCH_G=$G BENCH_FWD_G=$G BENCH_ONLY='$ONLY' timeout -s KILL 120 rocprofv3 --pmc $P --output-format csv -d \$GRAFT_REPO_ROOT/gpurun_out/traffic/${OP}_g${G}_$P -- python3 \$GRAFT_REPO_ROOT/tools/$SCRIPT > \$GRAFT_REPO_ROOT/gpurun_out/traffic/${OP}_g${G}_$P.out 2>&1"
   done
 done
 rm -rf gpurun_out/traffic
@@ -27,7 +29,7 @@ for d in sorted(glob.glob("gpurun_out/traffic/*_FETCH_SIZE")) + sorted(glob.glob
     for f in glob.glob(d + "/*/*counter_collection.csv"):
         for r in csv.DictReader(open(f)):
             kn = r["Kernel_Name"]
-            hit = "pconv_fused12" in kn if "fwd12" in op else ("gemm_kernel" in kn or "pconv_" in kn)
+            hit = "pconv_fused12" in kn if "fwd12" in op else ("gemm_kernel" in kn or "pconv_" in kn or "pconv4_" in kn)
             if hit and r["Counter_Name"] == counter:
                 vals.append(float(r["Counter_Value"])); name = r["Kernel_Name"]
     if vals:
