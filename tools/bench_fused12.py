@@ -1,5 +1,6 @@
 """HIP-event timing of the fused layers 1 + 2 of a no-gradient encoder pass (serl_convs_fwd12) against the two
-serl_convs_fwd launches it replaces, at the bench shapes (B = 256, 128 x 128 x 9 uint8 frames, G groups)."""
+serl_convs_fwd launches it replaces, at the bench shapes (B = 256, 128 x 128 x 9 uint8 frames, BENCH_G groups); BENCH_KEEP=1 times serl_convs_fwd12_keep as the
+update launches it (the last two groups keep layer 1's output and both ReLU byte masks)."""
 import os
 import sys
 
@@ -43,4 +44,10 @@ def two():
     ops.convs_fwd(p(y1), p(wf2), p(b2), p(y2), False, B, IH, IH, F1, 3, 3, 2, F2, True, st)
 
 
+if os.environ.get("BENCH_KEEP"):      # as the update's 4-group launch: the last two groups (the critic pass) keep layer 1's output + masks
+    rm1 = [torch.empty(B * IH * IH * F1 // 8, dtype=torch.uint8, device=dev) for _ in range(2)]
+    rm2 = [torch.empty(B * OH * OH * F2 // 8, dtype=torch.uint8, device=dev) for _ in range(2)]
+    ky1 = [0] * (G - 2) + p(y1[:2]); km1 = [0] * (G - 2) + p(rm1); km2 = [0] * (G - 2) + p(rm2)
+    print(f"G={G} keep: fused {timeit(lambda: ops.convs_fwd12_keep(p(xs), p(wf1), p(b1), p(wf2), p(b2), p(y2), B, IH1, IH1, C1, F1, F2, True, st, rmasks=km2, y1s=ky1, rmask1s=km1)):7.1f} us")
+    sys.exit(0)
 print(f"G={G}: two launches {timeit(two):7.1f} us   fused {timeit(lambda: ops.convs_fwd12(p(xs), p(wf1), p(b1), p(wf2), p(b2), p(y2), B, IH1, IH1, C1, F1, F2, True, st)):7.1f} us")

@@ -6,16 +6,18 @@ OUT=$1
 # <layer>_<op>@<groups>: forward launches carry 4 groups (target + critic passes) or 2 (actor run-ahead pass)
 # (since round 2 the driver launches: conv1 fwd with 2 groups (the differentiated pass), layers 1+2 of the other passes fused
 #  (fwd12, 2 groups per launch), conv2 fwd with 2 groups, conv3/conv4 fwd with 4 and 2 groups)
-OPS=${TRAFFIC_OPS:-"conv1_fwd@2 conv1_fwd12@2 conv1_wgrad@2 conv2_fwd@4 conv2_fwd@2 conv2_wgrad@2 conv2_dgrad@2 conv2_dgw1@2 conv3_fwd@4 conv3_fwd@2 conv3_wgrad@2 conv3_dgrad@2 conv4_fwd@4 conv4_fwd@2 conv4_wgrad@2 conv4_dgrad@2"}
+OPS=${TRAFFIC_OPS:-"conv1_fwd@2 conv1_fwd12@2 conv1_fwd12@4 conv1_fwd12keep@4 conv1_fwd12keep@2 conv1_wgrad@2 conv2_fwd@4 conv2_fwd@2 conv2_wgrad@2 conv2_dgrad@2 conv2_dgw1@2 conv3_fwd@4 conv3_fwd@2 conv3_wgrad@2 conv3_dgrad@2 conv4_fwd@4 conv4_fwd@2 conv4_wgrad@2 conv4_dgrad@2"}
 CMD="mkdir -p gpurun_out/traffic && cd /tmp && export TMPDIR=/tmp && export BENCH_N=2"
 for OPG in $OPS; do
   OP=${OPG%@*}; G=${OPG#*@}
   SCRIPT=bench_conv.py
+  KEEP=
   if [ "$OP" = conv1_fwd12 ]; then SCRIPT=bench_fused12.py; fi
+  if [ "$OP" = conv1_fwd12keep ]; then SCRIPT=bench_fused12.py; KEEP="BENCH_KEEP=1"; fi
   ONLY="${OP/_/ }"
   if [ "$OP" = conv2_dgw1 ]; then ONLY=dgw1; fi      # conv2's data gradient + conv1's weight gradient in one launch
   for P in FETCH_SIZE WRITE_SIZE; do
-    CMD="$CMD && BENCH_G=$G BENCH_FWD_G=$G BENCH_ONLY='$ONLY' timeout -s KILL 120 rocprofv3 --pmc $P --output-format csv -d \$GRAFT_REPO_ROOT/gpurun_out/traffic/${OP}_g${G}_$P -- python3 \$GRAFT_REPO_ROOT/tools/$SCRIPT > \$GRAFT_REPO_ROOT/gpurun_out/traffic/${OP}_g${G}_$P.out 2>&1"
+    CMD="$CMD && $KEEP BENCH_G=$G BENCH_FWD_G=$G BENCH_ONLY='$ONLY' timeout -s KILL 120 rocprofv3 --pmc $P --output-format csv -d \$GRAFT_REPO_ROOT/gpurun_out/traffic/${OP}_g${G}_$P -- python3 \$GRAFT_REPO_ROOT/tools/$SCRIPT > \$GRAFT_REPO_ROOT/gpurun_out/traffic/${OP}_g${G}_$P.out 2>&1"
   done
 done
 rm -rf gpurun_out/traffic
