@@ -52,7 +52,10 @@ int serl_conv2d_wgrad(int ngroups, const void* const* x, const float* const* dz,
  * aligned.  Activations (NHWC: rows = pixels, cols = channels) and their gradients stay in this format between
  * layers; the first layer reads uint8 pixels (KW*C <= 32).  serl_convs_prep_weights re-lays an HWIO fp32 kernel
  * out as wf (forward operand, serl_convs_weight_bytes bytes) and wd (data-gradient operand, 4*KH*KW*C*F bytes;
- * may be NULL).  No counterpart in the reference: XLA picks its own internal layouts. */
+ * may be NULL).  For a 3x3 layer with C = 128, F = 256 (the encoder's last layer) serl_convs_weight_bytes is twice the
+ * S-format size: behind the [F][2][K] image the same call writes the weights once more in the MFMA-fragment order of
+ * csrc/pconv4.h, which serl_convs_fwd streams from L2.  No counterpart in the reference: XLA picks its own internal
+ * layouts. */
 long long serl_convs_weight_bytes(int in_u8, int KH, int KW, int C, int F);
 int serl_split_f32(const float* in, void* out, long long rows, int cols, void* stream);
 int serl_merge_split(const void* in, float* out, long long rows, int cols, void* stream);
@@ -75,7 +78,9 @@ int serl_convs_fwd(int ngroups, const void* const* x, const void* const* wf, con
  * test of the paths; 2 = without the 4-wave kernels; 3 = plus the LDS-DMA ring GEMM (csrc/sgemm_ring.h) for the deep
  * layers; 4 = serl_convs_fwd12 on its one-set kernel (default: two wave sets half a period apart); 5 / 6 / 7 = as 1 but
  * serl_convs_dgrad_wgrad1_supported / serl_convs_fwd12_keep_supported answer 0 / the C = 64 -> F = 128 weight gradient stays
- * on the im2col kernel (A/B of the round-3 kernels).  Process-wide; no counterpart in the reference (XLA picks its
+ * on the im2col kernel; 8 = as 1 with the last layer's forward (15 x 15 x 128 -> 7 x 7 x 256, even B) on the im2col
+ * kernel instead of pconv4_fwd_kernel, whose K loop runs in another order: equal to one step of the S format's 16-bit
+ * mantissa, not bit for bit (A/B of the round-3 kernels).  Process-wide; no counterpart in the reference (XLA picks its
  * convolution algorithm itself, two_d4pg_encoder.py:30-38). */
 int serl_convs_set_patch_kernels(int enable);
 /* Persistent patch kernels launched after this call spread over at most `cus` compute units (0: all).  The step driver
