@@ -272,6 +272,7 @@ struct serl_learner {
   bool pol_fused = getenv("SERL_AMD_POL_FUSED") == nullptr || strcmp(getenv("SERL_AMD_POL_FUSED"), "0") != 0;   // A/B switch
   bool ens_bwd_fused = getenv("SERL_AMD_ENS_BWD_FUSED") == nullptr || strcmp(getenv("SERL_AMD_ENS_BWD_FUSED"), "0") != 0;   // A/B switch
   bool f12_keep = getenv("SERL_AMD_CONV_F12_KEEP") == nullptr || strcmp(getenv("SERL_AMD_CONV_F12_KEEP"), "0") != 0;   // A/B switch
+  bool actor_merge = getenv("SERL_AMD_ACTOR_MERGE") != nullptr && strcmp(getenv("SERL_AMD_ACTOR_MERGE"), "0") != 0;   // experiment (update loop)
   bool fuse_dgw1 = getenv("SERL_AMD_CONV_DGW1") == nullptr || strcmp(getenv("SERL_AMD_CONV_DGW1"), "0") != 0;   // A/B switch
   bool fuse12 = getenv("SERL_AMD_CONV_FUSE12") == nullptr || strcmp(getenv("SERL_AMD_CONV_FUSE12"), "0") != 0;   // A/B switch
   std::vector<TimeRec> trecs;
@@ -1120,7 +1121,8 @@ struct Feats {   // device inputs of the call, rows [0, n)
   int row0 = 0, total_rows = 0;                                        // global row of this rank's minibatch row 0 / global minibatch
 };
 // which: 0 obs, 1 next; drop: rngs={"dropout": key} of an apply call with training=True (NULL: no dropout)
-struct FPass { char tag; Store store; const EncOff* eo; int which; float* z; hipStream_t trunk_stream; const uint32_t* drop = nullptr; };
+struct FPass { char tag; Store store; const EncOff* eo; int which; float* z; hipStream_t trunk_stream; const uint32_t* drop = nullptr;
+               int lo = -1; };     // lo >= 0: this pass reads minibatch rows lo .. lo + B instead of the call's (merged run-ahead pass)
 
 // TwoMobileNetEncoder behind its frozen backbone (two_mobilenet_encoder.py:33-34): SpatialLearnedEmbeddings of the
 // minibatch rows of every pass (one grouped launch), then Dropout for the training passes.  The Dropout rng: flax folds
@@ -1172,14 +1174,15 @@ int features(serl_learner* h, const FPass* passes, int npass, const Feats& f, in
     Pass ep[4];
     for (int i = 0; i < npass; ++i) {
       ep[i].tag = passes[i].tag; ep[i].store = passes[i].store; ep[i].eo = passes[i].eo;
-      for (int ci = 0; ci < c.ncam; ++ci) ep[i].imgs[ci] = f.aug[passes[i].which][ci] + lo * img_bytes;
+      const size_t plo = passes[i].lo >= 0 ? passes[i].lo : lo;
+      for (int ci = 0; ci < c.ncam; ++ci) ep[i].imgs[ci] = f.aug[passes[i].which][ci] + plo * img_bytes;
     }
     DRV(encoder_fwd(h, ep, npass, B, ws, st, save_tag, prep));
   }
   if (fork)     // the trunks of the passes are independent: side streams wait for the encoders
     for (int i = 0; i < npass; ++i) DRV(link(st, passes[i].trunk_stream, fork));
   for (int i = 0; i < npass; ++i) {
-    const float* state = (passes[i].which ? f.next_state : f.state) + (size_t)lo * c.state_dim;
+    const float* state = (passes[i].which ? f.next_state : f.state) + (size_t)(passes[i].lo >= 0 ? passes[i].lo : lo) * c.state_dim;
     DRV(trunk_fwd(h, passes[i].tag, passes[i].store, *passes[i].eo, state, passes[i].z, c.ldz, B, ws, passes[i].trunk_stream,
                   passes[i].tag == save_tag));
   }
@@ -1626,18 +1629,31 @@ extern "C" int serl_learner_update(serl_learner* h, const serl_agent_buffers* ag
     DRV(target_members(h, &step_keys[8 * i + 2], target, ws, st, &m0, &mstride, &emin, &tstore));
     float* zT = zT_all + (size_t)i * B * ldz;
     float* zC = c.pixel ? zC1 : zC_all + (size_t)lo * ldz;
+    // SERL_AMD_ACTOR_MERGE=1 (experiment): the actor's run-ahead ENCODER pass of step i + 1 rides in the target + critic
+    // launches of step i as a third pass (6 groups per launch) instead of running next to the heads / backward phases
+    const bool merge_actor = h->actor_merge && c.pixel && c.encoder == 0 && sta != st && i + 1 < utd;
     if (c.pixel) {
       // target chain on the main stream, critic chain on a side stream, next action from the actor stream
-      FPass ps[2] = {{'T', target, &co.e, 1, zT, st, &step_keys[8 * i + 4]}, {'C', critic, &co.e, 0, zC, s1, &step_keys[8 * i + 6]}};
-      DRV(features(h, ps, 2, f, lo, B, ws, st, 'C', h->fork_ev, true));
+      FPass ps[3] = {{'T', target, &co.e, 1, zT, st, &step_keys[8 * i + 4]}, {'C', critic, &co.e, 0, zC, s1, &step_keys[8 * i + 6]},
+                     {'A', actor, &ao.e, 1, zA, sta, nullptr, (i + 1) * B}};
+      if (merge_actor) DRV_HIP(ev_wait(st, h->adone[i]));      // pass i's trunk has read enc_A before this launch overwrites it
+      DRV(features(h, ps, merge_actor ? 3 : 2, f, lo, B, ws, st, 'C', h->fork_ev, true));
     }
     DRV(phase(h, "features_fwd", st));
-    // start pass i+1 when the main stream leaves its encoder forward (round 3, re-measured with the fused kernels: behind
-    // the TD loss instead -1.3 %, in front of the encoder forward -16 % -- two persistent grids then share every CU's LDS)
-    DRV(link(st, sta, h->agate));
-    if (i + 1 < utd) DRV(enqueue_actor(i + 1));
-    else DRV(enqueue_actor_obs());
-    if (sta != st) DRV_HIP(ev_wait(st, h->adone[i]));
+    if (merge_actor) {
+      const int j = i + 1;
+      DRV(policy_fwd(h, 'A', actor, ao, zA, ldz, B, ws, sta, &step_keys[8 * j], rank * B, Bg,
+                     zT_all + ((size_t)j * B * ldz + c.latent), ldz, false, false, c.backup_entropy != 0,
+                     nlogp_all + (size_t)j * B, nullptr));
+      DRV_HIP(ev_record(h->adone[j], sta));
+    } else {
+      // start pass i+1 when the main stream leaves its encoder forward (round 3, re-measured with the fused kernels: behind
+      // the TD loss instead -1.3 %, in front of the encoder forward -16 % -- two persistent grids then share every CU's LDS)
+      DRV(link(st, sta, h->agate));
+      if (i + 1 < utd) DRV(enqueue_actor(i + 1));
+      else DRV(enqueue_actor_obs());
+      if (sta != st) DRV_HIP(ev_wait(st, h->adone[i]));
+    }
     float *next_q, *q;
     if (!multi && c.crit_drop <= 0.f && ens_fwd_fusable(h)) {
       // state-based learners: target and critic passes share the caller's stream -> one launch for both
