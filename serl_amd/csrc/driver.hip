@@ -256,7 +256,7 @@ struct serl_learner {
   hipStream_t comm = nullptr;
   hipEvent_t comm_fork = nullptr, comm_done = nullptr;
   bool dp_overlap = getenv("SERL_AMD_DP_OVERLAP") == nullptr || strcmp(getenv("SERL_AMD_DP_OVERLAP"), "0") != 0;
-  GradSide gside, gside2;   // gside2: every other conv weight gradient (SERL_AMD_WG_STREAMS=2), so that it starts when its dz is ready
+  GradSide gside, gside2;   // gside2 (experiments, default off): every other conv weight gradient (SERL_AMD_WG_STREAMS=2), or the heads' parameter gradients (=3)
   // CU cap of the run-ahead pass's persistent patch kernels (default 7/8 of the CUs, set at creation; 0: none).  Their
   // blocks otherwise hold every CU for ~100 us at a time and the short kernels of the critic step's latency-bound chain
   // wait for one to retire: 592.9 -> 596.5 grad-steps/s at 224 of 256 (three interleaved runs; 240: -0.3 %, 208: +0.2 %).
@@ -564,7 +564,8 @@ int encoder_bwd(serl_learner* h, char tag, const Store& store, const EncOff& eo,
     DRV(serl_sle_bwd(ncam, douts, c.enc_dim, kers, feats, dfeat, dker, B, HW, last.F, SLE_FEATURES, split, st));
   } else {
     hipStream_t sw;
-    DRV(gside->fork(&sw));
+    GradSide* const gs_sle = gside == &h->gside && h->wg_streams == 3 ? &h->gside2 : gside;   // (with the heads' gradients)
+    DRV(gs_sle->fork(&sw));
     DRV(serl_sle_bwd(ncam, douts, c.enc_dim, kers, feats, nullptr, dker, B, HW, last.F, SLE_FEATURES, split, sw));
     DRV(serl_sle_bwd(ncam, douts, c.enc_dim, kers, feats, dfeat, nullptr, B, HW, last.F, SLE_FEATURES, split, st));
   }
@@ -604,7 +605,7 @@ int encoder_bwd(serl_learner* h, char tag, const Store& store, const EncOff& eo,
     hipStream_t sw = st;
     float* slab_l = slab;
     if (gside && !on_main) {                        // dz of this layer is ready on the main stream here
-      if (gside == &h->gside && h->wg_streams > 1 && ((nl - 1 - li) & 1)) {
+      if (gside == &h->gside && h->wg_streams == 2 && ((nl - 1 - li) & 1)) {
         DRV(h->gside2.fork(&sw));
         WSF(ws, st, slab2, (size_t)slab_bytes / 4, "wgrad_slab2");
         slab_l = slab2;
@@ -1192,12 +1193,12 @@ int features(serl_learner* h, const FPass* passes, int npass, const Feats& f, in
 int features_bwd(serl_learner* h, char tag, const Store& store, const EncOff& eo, const Store& grads, const Feats& f, int lo,
                  int B, Workspace& ws, hipStream_t st, const float* dz, int lddz, bool need_encoder, GradSide* gside,
                  int dz_nslab, long long dz_ss, const uint32_t* drop = nullptr,
-                 const std::function<int()>* after_trunk = nullptr) {
+                 const std::function<int()>* after_trunk = nullptr, GradSide* gside_trunk = nullptr) {
   const Cfg& c = h->cfg;
   if (!c.pixel) return SERL_OK;   // no trainable feature stage for state inputs
   WSF(ws, st, z, (size_t)B * c.ldz, "z%c", tag);
   DRV(trunk_bwd(h, tag, store, eo, grads, f.state + (size_t)lo * c.state_dim, z, c.ldz, dz, lddz, B, ws, st, need_encoder,
-                gside, dz_nslab, dz_ss));
+                gside_trunk ? gside_trunk : gside, dz_nslab, dz_ss));
   // every gradient kernel of the ensemble and trunk leaves is enqueued: the data-parallel bucket of those leaves starts here
   if (after_trunk) DRV((*after_trunk)());
   if (need_encoder && c.encoder == 1) {
@@ -1676,7 +1677,10 @@ extern "C" int serl_learner_update(serl_learner* h, const serl_agent_buffers* ag
     // pixel learners: the trunk backward sums the split-K slabs of the input gradient on read; state-based:
     // observations are not trainable, the critic step needs no input gradient at all
     float* dinp = nullptr; int nslab = 1; long long ss = 0;
-    DRV(ensemble_bwd(h, 'C', critic, co, &cgr, dq, zC, ldz, B, ws, st, &h->gside, c.pixel ? 2 : 0, &dinp, &nslab, &ss,
+    // SERL_AMD_WG_STREAMS=3: the heads' parameter gradients (ensemble, trunk) on a side stream of their own, so that the conv
+    // weight gradients start when their dz is ready instead of behind ~200 us of small GEMMs
+    GradSide* const gs_heads = multi && h->wg_streams == 3 ? &h->gside2 : &h->gside;
+    DRV(ensemble_bwd(h, 'C', critic, co, &cgr, dq, zC, ldz, B, ws, st, gs_heads, c.pixel ? 2 : 0, &dinp, &nslab, &ss,
                      &step_keys[8 * i + 6], rank * B, Bg));
     DRV(phase(h, "ensemble_bwd", st));
     // data parallel, pixel learners: two buckets.  Bucket 4 = the trunk + ensemble leaves (the suffix of the flat gradient:
@@ -1685,7 +1689,7 @@ extern "C" int serl_learner_update(serl_learner* h, const serl_agent_buffers* ag
     // gradient is in.  The hook enqueues bucket 4 on the stream serl_learner_comm_stream returns.
     const bool dp_overlap = world > 1 && multi && h->dp_overlap;
     const std::function<int()> bucket4 = [&]() -> int {
-      DRV(link(h->gside.side, h->comm, h->comm_fork));
+      DRV(link(gs_heads->side, h->comm, h->comm_fork));
       DRV(allreduce(allreduce_ctx, 4));
       DRV_HIP(ev_record(h->comm_done, h->comm));
       return SERL_OK;
@@ -1695,7 +1699,7 @@ extern "C" int serl_learner_update(serl_learner* h, const serl_agent_buffers* ag
       DRV(serl_learner_comm_stream(h, &unused));
     }
     DRV(features_bwd(h, 'C', critic, co.e, cgr, f, lo, B, ws, st, dinp, ldz, true, &h->gside, nslab, ss, &step_keys[8 * i + 6],
-                     dp_overlap ? &bucket4 : nullptr));
+                     dp_overlap ? &bucket4 : nullptr, gs_heads));
     DRV(h->gside.join());
     DRV(h->gside2.join());
     DRV(phase(h, "features_bwd", st));
