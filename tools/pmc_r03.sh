@@ -30,9 +30,11 @@ NAMES = [("pconv_fused12pp_kernel", "layers 1+2 fused, no-gradient passes (pconv
          ("pconv_dgw1_kernel", "conv2 data gradient + conv1 weight gradient in one kernel (pconv_dgw1_kernel), 2 groups"),
          ("pconv_fwdw_kernel", "conv3 forward wide patch kernel (pconv_fwdw_kernel), 4 groups"),
          ("pconv_dgradw_kernel", "conv3 data gradient wide patch kernel (pconv_dgradw_kernel), 2 groups"),
+         ("pconv4_fwd_kernel", "conv4 forward, parity-class patch kernel (pconv4_fwd_kernel), 4 groups"),
+         ("pconv_wgradw_kernel", "conv3 weight gradient wide patch kernel (pconv_wgradw_kernel), 2 groups"),
          ("sgemm_kernel<ConvFwdS<false>", "conv4 forward, register-staged im2col (sgemm_kernel<ConvFwdS>), 4 groups"),
          ("sgemm_kernel<ConvDgradS", "conv4 data gradient (sgemm_kernel<ConvDgradS>), 2 groups"),
-         ("sgemm_kernel<ConvWgradS<false>", "conv3 + conv4 weight gradients (sgemm_kernel<ConvWgradS<false>>), 2 groups, averaged"),
+         ("sgemm_kernel<ConvWgradS<false>", "conv4 weight gradient (sgemm_kernel<ConvWgradS<false>>; before round 3's conv3 patch kernel: conv3 + conv4 averaged), 2 groups"),
          ("sgemm_kernel<ConvWgradS<true>", "conv1 weight gradient, uint8 input (sgemm_kernel<ConvWgradS<true>>), 2 groups"),
          ("wgrad_reduce_kernel", "split-K slab reduction (wgrad_reduce_kernel), averaged over the layers")]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
