@@ -52,9 +52,10 @@ int serl_conv2d_wgrad(int ngroups, const void* const* x, const float* const* dz,
  * aligned.  Activations (NHWC: rows = pixels, cols = channels) and their gradients stay in this format between
  * layers; the first layer reads uint8 pixels (KW*C <= 32).  serl_convs_prep_weights re-lays an HWIO fp32 kernel
  * out as wf (forward operand, serl_convs_weight_bytes bytes) and wd (data-gradient operand, 4*KH*KW*C*F bytes;
- * may be NULL).  For a 3x3 layer with C = 128, F = 256 (the encoder's last layer) serl_convs_weight_bytes is twice the
- * S-format size: behind the [F][2][K] image the same call writes the weights once more in the MFMA-fragment order of
- * csrc/pconv4.h, which serl_convs_fwd streams from L2.  No counterpart in the reference: XLA picks its own internal
+ * may be NULL).  For a 3x3 layer with C = 128, F = 256 (the encoder's last layer) or C = 64, F = 128 (the one before)
+ * serl_convs_weight_bytes is twice the S-format size: behind the [F][2][K] image the same call writes the weights once
+ * more in the MFMA-fragment order of the kernel that serl_convs_fwd runs for that shape (csrc/pconv4.h streams them from
+ * L2, pconv_fwdw_kernel loads them into its registers as one span per wave).  No counterpart in the reference: XLA picks its own internal
  * layouts. */
 long long serl_convs_weight_bytes(int in_u8, int KH, int KW, int C, int F);
 int serl_split_f32(const float* in, void* out, long long rows, int cols, void* stream);

@@ -385,8 +385,9 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(const PrepArgs a) {
       }
       if (a.wq4) {
         ushort_t* wq = a.wf[gi] + (size_t)2 * a.Kp * a.F;
-        wq[p4_wq_index(k, f, 0)] = h;
-        wq[p4_wq_index(k, f, 1)] = l;
+        const long long i0 = a.wq4 == 1 ? p4_wq_index(k, f, 0) : pfw_wq_index(k, f, 0, a.Kp);
+        wq[i0] = h;
+        wq[i0 + 512] = l;          // the lo plane's fragment follows the hi plane's (64 lanes x 8)
       }
     }
     th[ty + 8 * i][tx] = h; tl[ty + 8 * i][tx] = l;
@@ -436,8 +437,9 @@ __global__ __launch_bounds__(256) void prep_weights_multi_kernel(const PrepJobs 
       }
       if (a.wq4[j]) {
         ushort_t* wq = wf + (size_t)2 * Kp * F;
-        wq[p4_wq_index(k, f, 0)] = h;
-        wq[p4_wq_index(k, f, 1)] = l;
+        const long long i0 = a.wq4[j] == 1 ? p4_wq_index(k, f, 0) : pfw_wq_index(k, f, 0, Kp);
+        wq[i0] = h;
+        wq[i0 + 512] = l;          // the lo plane's fragment follows the hi plane's (64 lanes x 8)
       }
     }
     th[ty + 8 * i][tx] = h; tl[ty + 8 * i][tx] = l;
@@ -533,8 +535,12 @@ static bool all_aligned16(const void* const* ps, int n) {
 
 static int s_kp(int in_u8, int KH, int KW, int C) { return in_u8 ? KH * 32 : KH * KW * C; }
 
-// the last encoder layer's shape keeps a second image of its weights (pconv4.h: fragment order of pconv4_fwd_kernel) behind wf
-static bool s_wq4(int in_u8, int KH, int KW, int C, int F) { return !in_u8 && KH == 3 && KW == 3 && C == 128 && F == 256; }
+// two layer shapes keep a second image of their weights behind wf, in the MFMA-fragment order of the kernel that reads it:
+// 1 = 3x3, 128 -> 256 (pconv4.h, pconv4_fwd_kernel), 2 = 3x3, 64 -> 128 (pconv.h, pconv_fwdw_kernel)
+static int s_wq4(int in_u8, int KH, int KW, int C, int F) {
+  if (in_u8 || KH != 3 || KW != 3) return 0;
+  return C == 128 && F == 256 ? 1 : (C == 64 && F == 128 ? 2 : 0);
+}
 extern "C" long long serl_convs_weight_bytes(int in_u8, int KH, int KW, int C, int F) {
   return 4ll * s_kp(in_u8, KH, KW, C) * F * (s_wq4(in_u8, KH, KW, C, F) ? 2 : 1);
 }
@@ -661,7 +667,7 @@ extern "C" int serl_convs_fwd(int ngroups, const void* const* x, const void* con
     }
     if (fit16) {
       PConvFwdArgs a;
-      a.B = B; a.IH = IH; a.IW = IW; a.OH = g.OH; a.OW = g.OW; a.relu = relu;
+      a.B = B; a.IH = IH; a.IW = IW; a.OH = g.OH; a.OW = g.OW; a.relu = relu; a.wfrag = 1;
       a.nbands = cdiv(g.OH, 4);
       a.d_iw = make_fastdiv(IW); a.d_bands = make_fastdiv(a.nbands);
       for (int i = 0; i < ngroups; ++i) {

@@ -33,8 +33,14 @@ struct PConvFwdArgs {
   unsigned short* y[MAXG];
   unsigned char* rmask[MAXG];
   int B, IH, IW, OH, OW, nbands, relu;
+  int wfrag = 0;                      // the fragment-ordered image (pfw_wq_index) follows wf's 2 * F * Kp values
   FastDiv d_iw, d_bands;
 };
+// position (bf16 units) of weight (k, f) of a plane in pconv_fwdw_kernel's fragment-ordered image:
+// [wave = f / 32][k16 step][plane][lane = 32 (k % 16 / 8) + f % 32][k % 8] -- a wave reads its 2 KB per step as one span
+__host__ __device__ inline long long pfw_wq_index(int k, int f, int plane, int Kp) {
+  return ((((long long)(f >> 5) * (Kp >> 4) + (k >> 4)) * 2 + plane) * 64 + ((k >> 3) & 1) * 32 + (f & 31)) * 8 + (k & 7);
+}
 
 // C, F: channels in / out; R: output rows per item; OWP: padded output width (power of two, 32 % OWP == 0).
 // 8 waves = (M tiles) x (N tiles) of an item, one 32 x 32 accumulator per wave.
@@ -405,10 +411,21 @@ __global__ __launch_bounds__(G::NT, 1) void pconv_fwdw_kernel(const PConvFwdArgs
 #else
     const unsigned short* wrow = a.wf[z] + (size_t)((wid * 32 + r) * 2) * Kp + h * 8;
 #endif
+    if (a.wfrag) {
+      // round 3: serl_convs_prep_weights also writes the fragments in the order this loop wants them (72 KB per wave, one
+      // contiguous span; walking the [F][2][Kp] rows made every lane fetch its own cache line: ~15 us per block)
+      const u32x4_t* wq = reinterpret_cast<const u32x4_t*>(a.wf[z] + (size_t)2 * F * Kp) + (size_t)wid * NS * 128 + lane;
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      rbh[s] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(wrow + s * 16));
-      rbl[s] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(wrow + Kp + s * 16));
+      for (int s = 0; s < NS; ++s) {
+        rbh[s] = __builtin_bit_cast(bf16x8_t, wq[s * 128]);
+        rbl[s] = __builtin_bit_cast(bf16x8_t, wq[s * 128 + 64]);
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        rbh[s] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(wrow + s * 16));
+        rbl[s] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(wrow + Kp + s * 16));
+      }
     }
   }
 
