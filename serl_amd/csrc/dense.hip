@@ -5,6 +5,7 @@
 //   C[z][m][n] (+)= sum_k A[z][m][k] * B[z][k][n]          z = blockIdx.z (ensemble member)
 //   A elem = a[z*a_zs + seg*a_ss + m*a_ms + r*a_ks],  B elem = b[z*b_zs + seg*b_ss + r*b_ks + n*b_ns]
 //   with k = seg*seglen + r  (segments let one GEMM reduce over (member, feature) pairs).
+#include <stdlib.h>
 #include "igemm_bf3.h"
 
 #ifndef GEMM_DEPTH
@@ -114,7 +115,8 @@ extern "C" int serl_gemm(const float* a, const float* b, float* c, const float* 
   const int ns = cdiv(K, klen);
   SERL_CHECK_ARG(ns == nsplit, "gemm: nsplit %d does not tile K=%d in multiples of 16 (got %d)", nsplit, K, ns);
   hipStream_t st = (hipStream_t)stream;
-  const bool big = (M >= 512 && N >= 512);
+  static const int big_n = getenv("SERL_AMD_GEMM_BIGN") ? atoi(getenv("SERL_AMD_GEMM_BIGN")) : 512;   // A/B switch
+  const bool big = (M >= 512 && N >= big_n);
   // float4 loads along the contiguous axis when every vector of 4 is aligned, contiguous and all-or-nothing valid
   auto m4 = [](long long v) { return (v & 3) == 0; };
   const bool a4 = (((uintptr_t)a) & 15) == 0 && m4(a_zs) && m4(a_ss) &&

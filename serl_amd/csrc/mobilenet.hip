@@ -130,12 +130,23 @@ __global__ __launch_bounds__(256) void dw_kernel(const DwArgs a) {
 }
 
 // ---- squeeze: out[img][c] = mean over the HW pixels; block = (image, 64 channels), 4 pixel phases x 64 channels
-__global__ __launch_bounds__(256) void se_pool_kernel(const float* x, float* out, int HW, int C) {
+__global__ __launch_bounds__(256) void se_pool_kernel(const float* __restrict__ x, float* __restrict__ out, int HW, int C) {
   __shared__ float red[4][64];
   const int img = blockIdx.x, c = blockIdx.y * 64 + (threadIdx.x & 63), ph = threadIdx.x >> 6;
   float s = 0.f;
-  if (c < C)
-    for (int p = ph; p < HW; p += 4) s += x[((long long)img * HW + p) * C + c];
+  if (c < C) {
+    // 16 loads in flight per thread (the adds keep their order: same bits); a rolled loop was one round trip per pixel
+    const float* px = x + (long long)img * HW * C + c;
+    int p = ph;
+    for (; p + 60 < HW; p += 64) {
+      float v[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[j] = px[(long long)(p + 4 * j) * C];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) s += v[j];
+    }
+    for (; p < HW; p += 4) s += px[(long long)p * C];
+  }
   red[ph][threadIdx.x & 63] = s;
   __syncthreads();
   if (ph == 0 && c < C) out[(long long)img * C + c] = (red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]) / (float)HW;
