@@ -94,6 +94,9 @@ typedef TileCfg<128, 128, 32, 2, 2> B128x128;
 
 // layout codes: a_kcontig = 1 when consecutive k of A are adjacent in memory (else consecutive m are),
 //               b_ncontig = 1 when consecutive n of B are adjacent (else consecutive k are).
+static thread_local int g_gemm_big_n = 0;
+void serl_gemm_set_big_n(int n) { g_gemm_big_n = n; }
+
 extern "C" int serl_gemm(const float* a, const float* b, float* c, const float* bias, int nbatch, int M, int N, int K,
                          int seglen, long long a_zs, long long a_ss, long long a_ms, long long a_ks, long long b_zs,
                          long long b_ss, long long b_ks, long long b_ns, long long c_zs, long long c_ms,
@@ -115,8 +118,11 @@ extern "C" int serl_gemm(const float* a, const float* b, float* c, const float* 
   const int ns = cdiv(K, klen);
   SERL_CHECK_ARG(ns == nsplit, "gemm: nsplit %d does not tile K=%d in multiples of 16 (got %d)", nsplit, K, ns);
   hipStream_t st = (hipStream_t)stream;
-  static const int big_n = getenv("SERL_AMD_GEMM_BIGN") ? atoi(getenv("SERL_AMD_GEMM_BIGN")) : 512;   // A/B switch
-  const bool big = (M >= 512 && N >= big_n);
+  // 128 x 128 tiles from this many columns on (and 512 rows): 512 for the learner's dense layers; the frozen MobileNetV3's
+  // pointwise convs (16 k .. 1 M rows x 80 .. 960 columns, memory-bound: fewer re-reads and re-splits of the activation
+  // operand per column tile) lower it for their calls (serl_gemm_set_big_n, per calling thread).  Same bits either way:
+  // every tile walks k in the same order.
+  const bool big = (M >= 512 && N >= (g_gemm_big_n > 0 ? g_gemm_big_n : 512));
   // float4 loads along the contiguous axis when every vector of 4 is aligned, contiguous and all-or-nothing valid
   auto m4 = [](long long v) { return (v & 3) == 0; };
   const bool a4 = (((uintptr_t)a) & 15) == 0 && m4(a_zs) && m4(a_ss) &&

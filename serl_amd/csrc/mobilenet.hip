@@ -15,6 +15,8 @@
 #include "common.h"
 #include "igemm_bf3.h"
 
+void serl_gemm_set_big_n(int n);     // dense.hip: column threshold of serl_gemm's 128 x 128 tiles for the calling thread (0: default)
+
 namespace {
 
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
@@ -493,7 +495,11 @@ int pointwise(const float* x, const float* w, const float* b, float* y, long lon
     PW_CASE(1, 1) PW_CASE(1, 2) PW_CASE(2, 1) PW_CASE(2, 3) PW_CASE(3, 1) PW_CASE(3, 2) PW_CASE(4, 1) PW_CASE(5, 1) PW_CASE(5, 2)
 #undef PW_CASE
   }
-  return serl_gemm(x, w, y, b, 1, (int)M, N, K, K, 0, 0, K, 1, 0, 0, N, 1, 0, N, 0, 1, 0, act, accumulate, 1, 1, st);
+  // (128 x 128 tiles from 64 columns on: 4.72 -> 4.50 ms per 1 024-image chain against serl_gemm's default of 512)
+  serl_gemm_set_big_n(64);
+  const int e = serl_gemm(x, w, y, b, 1, (int)M, N, K, K, 0, 0, K, 1, 0, 0, N, 1, 0, N, 0, 1, 0, act, accumulate, 1, 1, st);
+  serl_gemm_set_big_n(0);
+  return e;
 }
 
 struct Offsets { long long stem_k, stem_b, exp_k[NBLK], exp_b[NBLK], dw_k[NBLK], dw_b[NBLK], ser_k[NBLK], ser_b[NBLK],
