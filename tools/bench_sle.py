@@ -17,3 +17,18 @@ a.record()
 for _ in range(50): fn()
 b.record(); torch.cuda.synchronize()
 print(f"sle_fwd G={G}: {a.elapsed_time(b) / 50 * 1e3:.1f} us")
+
+# data gradient (critic pass: 2 groups, ReLU mask from the features) and kernel gradient
+G2 = 2
+dout = [torch.randn(B, 4096, device=dev) for _ in range(G2)]
+dfeat = [torch.empty(B * HW * 2 * C, dtype=torch.int16, device=dev) for _ in range(G2)]
+dker = [torch.empty(HW * C * 8, device=dev) for _ in range(G2)]
+p = lambda ts: [t.data_ptr() for t in ts]
+for name, fn2 in (("sle_bwd data", lambda: ops.sle_bwd(p(dout), 4096, p(ker[:G2]), p(feat[:G2]), p(dfeat), None, B, HW, C, 8, st, feat_split=True)),
+                  ("sle_bwd kernel", lambda: ops.sle_bwd(p(dout), 4096, p(ker[:G2]), p(feat[:G2]), None, p(dker), B, HW, C, 8, st, feat_split=True))):
+    for _ in range(5): fn2()
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(50): fn2()
+    b.record(); torch.cuda.synchronize()
+    print(f"{name} G={G2}: {a.elapsed_time(b) / 50 * 1e3:.1f} us")
