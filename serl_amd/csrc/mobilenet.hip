@@ -270,6 +270,108 @@ int pw_stream_launch(const float* x, const float* w, const float* b, float* y, l
   return SERL_OK;
 }
 
+// ---- block 0 (no expand: depthwise 3x3 stride 1 + ReLU -> 1x1 project 16 -> 16 + bias + residual) in one kernel.  The two
+// launches moved the block's 16-channel tensor (268 MB per 1 024 images) five times (read x, write d, read d, read and
+// write x); here it is read once and written once, OUT OF PLACE (a pixel's neighbours are other lanes' outputs).  The
+// kernel is pw_stream_kernel<1, 1> with the A operand computed instead of loaded: lane (pixel r, h) runs dw_kernel's tap
+// loop for channels 8 h .. 8 h + 7 of its pixel (taps outside the image add fmaf(0, w, acc) = acc; loads unconditional from
+// clamped coordinates, the next tile's taps requested before the current tile's arithmetic), the 8 results are split and
+// multiplied exactly as pw_stream_kernel does, and the residual is the block input at the same position: same bits as
+// dw_kernel + pw_stream_kernel(accumulate).
+struct DwPwArgs {
+  const float* x; const float* wd; const float* bd; const float* wp; const float* bp; float* y;
+  int H, W, pt, pl, M;
+  FastDiv d_hw, d_w;
+};
+__device__ float4 g_mb_zero[2];            // 32 bytes of zeros (never written): what a tap outside the image reads
+__global__ __launch_bounds__(256) void dwpw16_kernel(const DwPwArgs a) {
+  constexpr int C = 16;
+  __shared__ __attribute__((aligned(16))) float sw[10 * C];     // depthwise weights [9][16], then the bias
+  for (int i = threadIdx.x; i < 10 * C; i += 256) sw[i] = i < 9 * C ? a.wd[i] : a.bd[i - 9 * C];
+  const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+  // The product is computed TRANSPOSED (out^T = Wp^T d^T): the weights are the MFMA's A operand -- lane (n = r, h) holds
+  // Wp[8 h + j][r], j < 8, the registers pw_stream_kernel uses as its B fragment -- and the depthwise results the B operand
+  // (lane (pixel r, h) holds channels 8 h + j, pw_stream_kernel's A fragment).  The same products summed over the same k:
+  // the same bits; but the accumulator now holds, for the lane's OWN pixel, output channels 4 h .. 4 h + 3 and 8 + 4 h .. + 3
+  // (q = 0..3, 4..7): two 16-byte stores and two 16-byte residual loads per lane instead of sixteen 4-byte ones.
+  bf16x8_t wh, wl;
+  {
+    u32x4_t hv, lv;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int k0 = 8 * h + 2 * e;
+      const float w0 = r < C ? a.wp[k0 * C + r] : 0.f, w1 = r < C ? a.wp[(k0 + 1) * C + r] : 0.f;
+      uint32_t hh, ll;
+      split_pair(w0, w1, hh, ll);
+      hv[e] = hh; lv[e] = ll;
+    }
+    wh = __builtin_bit_cast(bf16x8_t, hv);
+    wl = __builtin_bit_cast(bf16x8_t, lv);
+  }
+  const float4 bs0 = *reinterpret_cast<const float4*>(a.bp + 4 * h), bs1 = *reinterpret_cast<const float4*>(a.bp + 8 + 4 * h);
+  __syncthreads();
+  const int ntiles = (a.M + 31) / 32, HW = a.H * a.W;
+  const float* const zero = reinterpret_cast<const float*>(g_mb_zero);
+  auto load_taps = [&](int tile, float4 (&v)[9][2]) {
+    int m = tile * 32 + r;
+    if (tile >= ntiles || m >= a.M) m = 0;                  // (valid memory; never stored)
+    const int img = (int)fd_div((uint32_t)m, a.d_hw), rem = m - img * HW, oy = (int)fd_div((uint32_t)rem, a.d_w), ox = rem - oy * a.W;
+    const float* ximg = a.x + (size_t)img * HW * C + 8 * h;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int iy = oy + ky - a.pt, ix = ox + kx - a.pl;
+        const bool in = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        // a tap outside the image reads zeros (pointer select, no data select): fmaf(0, w, acc) = acc, as dw_kernel's skip
+        const float4* p = reinterpret_cast<const float4*>(in ? ximg + ((size_t)iy * a.W + ix) * C : zero);
+        v[ky * 3 + kx][0] = p[0]; v[ky * 3 + kx][1] = p[1];
+      }
+  };
+  float4 cur[9][2], nxt[9][2];
+  load_taps(wave, cur);
+  for (int tile = wave; tile < ntiles; tile += nwaves) {
+    load_taps(tile + nwaves, nxt);
+    // depthwise conv of this lane's pixel, channels 8 h .. 8 h + 7 (dw_kernel's order: bias, then the taps (ky, kx) ascending)
+    float4 d0 = *reinterpret_cast<const float4*>(sw + 9 * C + 8 * h), d1 = *reinterpret_cast<const float4*>(sw + 9 * C + 8 * h + 4);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const float4 w0 = *reinterpret_cast<const float4*>(sw + t * C + 8 * h), w1 = *reinterpret_cast<const float4*>(sw + t * C + 8 * h + 4);
+      const float4 v0 = cur[t][0], v1 = cur[t][1];
+      d0.x = fmaf(v0.x, w0.x, d0.x); d0.y = fmaf(v0.y, w0.y, d0.y); d0.z = fmaf(v0.z, w0.z, d0.z); d0.w = fmaf(v0.w, w0.w, d0.w);
+      d1.x = fmaf(v1.x, w1.x, d1.x); d1.y = fmaf(v1.y, w1.y, d1.y); d1.z = fmaf(v1.z, w1.z, d1.z); d1.w = fmaf(v1.w, w1.w, d1.w);
+    }
+    u32x4_t hv, lv;
+    uint32_t hh, ll;
+    split_pair(fmaxf(d0.x, 0.f), fmaxf(d0.y, 0.f), hh, ll); hv[0] = hh; lv[0] = ll;
+    split_pair(fmaxf(d0.z, 0.f), fmaxf(d0.w, 0.f), hh, ll); hv[1] = hh; lv[1] = ll;
+    split_pair(fmaxf(d1.x, 0.f), fmaxf(d1.y, 0.f), hh, ll); hv[2] = hh; lv[2] = ll;
+    split_pair(fmaxf(d1.z, 0.f), fmaxf(d1.w, 0.f), hh, ll); hv[3] = hh; lv[3] = ll;
+    const bf16x8_t ah = __builtin_bit_cast(bf16x8_t, hv), al = __builtin_bit_cast(bf16x8_t, lv);
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, al, acc, 0, 0, 0);      // (pw_stream_kernel's order: lo x hi, hi x lo, hi x hi)
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, ah, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, ah, acc, 0, 0, 0);
+    const int m = tile * 32 + r;
+    if (m < a.M) {
+      const float4* xr = reinterpret_cast<const float4*>(a.x + (size_t)m * C + 4 * h);     // the residual: the block's input
+      float4* yr = reinterpret_cast<float4*>(a.y + (size_t)m * C + 4 * h);
+      const float4 x0 = xr[0], x1 = xr[2];
+      float4 o0, o1;
+      o0.x = acc[0] + bs0.x; o0.x += x0.x; o0.y = acc[1] + bs0.y; o0.y += x0.y;
+      o0.z = acc[2] + bs0.z; o0.z += x0.z; o0.w = acc[3] + bs0.w; o0.w += x0.w;
+      o1.x = acc[4] + bs1.x; o1.x += x1.x; o1.y = acc[5] + bs1.y; o1.y += x1.y;
+      o1.z = acc[6] + bs1.z; o1.z += x1.z; o1.w = acc[7] + bs1.w; o1.w += x1.w;
+      yr[0] = o0; yr[2] = o1;
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) { cur[t][0] = nxt[t][0]; cur[t][1] = nxt[t][1]; }
+  }
+}
+
 // ---- 1x1 expand + depthwise k x k in one kernel for the high-resolution blocks: the expanded tensor (4x / 3x the block's
 // input, the largest tensors of the network: 1.07 GB per 1024 images in block 1) is never written to memory.  A block
 // of 4 waves owns a TO x TO tile of depthwise OUTPUT pixels of one image: (i) its TI x TI input pixels (TI = (TO - 1) S +
@@ -463,6 +565,10 @@ int exp_dw_launch(EdArgs a, hipStream_t st) {
 }
 
 int g_mbv3_fused = -1;      // serl_mbv3_set_fused (A/B and the bit-identity test); -1: SERL_AMD_MBV3_FUSE, default on
+bool mbv3_fused_on() {
+  if (g_mbv3_fused < 0) g_mbv3_fused = getenv("SERL_AMD_MBV3_FUSE") == nullptr || strcmp(getenv("SERL_AMD_MBV3_FUSE"), "0") != 0;
+  return g_mbv3_fused != 0;
+}
 // returns 1 when a fused kernel took the expand + depthwise pair of this block, 0 when the caller runs the two launches
 int expand_depthwise_fused(const float* x, const float* we, const float* be, const float* wd, const float* bd, float* y, int n,
                            int H, int W, int K, int CE, int OH, int OW, int k, int s, int pt, int pl, int act, hipStream_t st,
@@ -619,6 +725,19 @@ extern "C" int serl_mbv3_forward(const float* params, const void* images, int in
     if (b.ir && !fused) {
       if (int e = pointwise(xin, params + o.exp_k[i], params + o.exp_b[i], E, M, cin, b.exp, b.act, 0, st)) return e;
       dwin = E;
+    }
+    // block 0: depthwise + projection + residual in one kernel, out of place (dwpw16_kernel)
+    if (!b.ir && b.k == 3 && b.s == 1 && b.exp == 16 && b.cout == 16 && cin == 16 && !b.se && b.act == ACT_RELU &&
+        serl_get_matmul_precision() == 1 && mbv3_fused_on() && M < (1ll << 31) / 16) {
+      DwPwArgs a{xin, params + o.dw_k[i], params + o.dw_b[i], params + o.pr_k[i], params + o.pr_b[i], X[cur ^ 1], h, w, pt, pl_, (int)M,
+                 make_fastdiv((uint32_t)(h * w)), make_fastdiv((uint32_t)w)};
+      const int ntiles = (int)((M + 31) / 32);
+      int blocks = (ntiles + 3) / 4;
+      if (blocks > 256 * 8) blocks = 256 * 8;
+      hipLaunchKernelGGL(dwpw16_kernel, dim3(blocks), dim3(256), 0, st, a);
+      SERL_CHECK_LAUNCH("mbv3 depthwise + projection");
+      cur ^= 1;
+      continue;              // (stride 1, 16 -> 16: h, w, cin unchanged)
     }
     if (!fused) {
       DwArgs a{dwin, params + o.dw_k[i], params + o.dw_b[i], D, n, h, w, b.exp / 4, oh, ow, b.k, b.s, pt, pl_, b.act};
