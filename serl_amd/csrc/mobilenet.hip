@@ -180,11 +180,9 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const float* __restrict_
   const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
   // B fragments: lane (n = r, h) holds W[16 s + 8 h + j][32 t + r], j < 8
   bf16x8_t bh[KS][NTL], bl[KS][NTL];
-  float bs[NTL];
 #pragma unroll
   for (int t = 0; t < NTL; ++t) {
     const int n = 32 * t + r;
-    bs[t] = n < N ? bias[n] : 0.f;
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       u32x4_t hv, lv;
@@ -233,26 +231,36 @@ __global__ __launch_bounds__(256) void pw_stream_kernel(const float* __restrict_
       split_pair(cur[s][1].x, cur[s][1].y, hh, ll); hv[2] = hh; lv[2] = ll;
       split_pair(cur[s][1].z, cur[s][1].w, hh, ll); hv[3] = hh; lv[3] = ll;
       const bf16x8_t ah = __builtin_bit_cast(bf16x8_t, hv), al = __builtin_bit_cast(bf16x8_t, lv);
+      // The product is computed TRANSPOSED (Y^T = W^T X^T: the weight fragments are the MFMA's A operand, the rows' its B
+      // operand -- the same registers, the same products summed over the same k: the same bits), so that a lane ends up
+      // with 4 consecutive output channels of its OWN row per accumulator quad: 16-byte stores (and residual loads)
+      // instead of 4-byte ones scattered over 16 rows.
 #pragma unroll
       for (int t = 0; t < NTL; ++t) {
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[s][t], acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[s][t], acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[s][t], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[s][t], al, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[s][t], ah, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[s][t], ah, acc[t], 0, 0, 0);
       }
     }
+    const int m = tile * 32 + r;
+    if (m < M) {
 #pragma unroll
-    for (int t = 0; t < NTL; ++t) {
-      const int n = 32 * t + r;
+      for (int t = 0; t < NTL; ++t)
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int m = tile * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-        if (m < M && n < N) {
-          float v = act_apply(acc[t][q] + bs[t], act);
-          float* dst = y + (size_t)m * N + n;
-          if (accumulate) v += *dst;
-          *dst = v;
+        for (int g = 0; g < 4; ++g) {
+          const int n0 = 32 * t + 8 * g + 4 * h;          // accumulator elements 4 g .. 4 g + 3: channels n0 .. n0 + 3 (N % 4 == 0)
+          if (n0 < N) {
+            const float4 b4 = *reinterpret_cast<const float4*>(bias + n0);
+            float4* dst = reinterpret_cast<float4*>(y + (size_t)m * N + n0);
+            float4 v = make_float4(act_apply(acc[t][4 * g] + b4.x, act), act_apply(acc[t][4 * g + 1] + b4.y, act),
+                                   act_apply(acc[t][4 * g + 2] + b4.z, act), act_apply(acc[t][4 * g + 3] + b4.w, act));
+            if (accumulate) {
+              const float4 o = *dst;
+              v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+            }
+            *dst = v;
+          }
         }
-      }
     }
 #pragma unroll
     for (int s = 0; s < KS; ++s) { cur[s][0] = nxt[s][0]; cur[s][1] = nxt[s][1]; }
@@ -594,7 +602,8 @@ int pointwise(const float* x, const float* w, const float* b, float* y, long lon
   SERL_CHECK_ARG(M * (long long)(K > N ? K : N) < (1ll << 31), "mobilenet: chunk too large for 32-bit tensor offsets");
   // (chosen by K and N only, never by M: a batch computed in chunks must give the bits of the whole batch)
   static const bool stream_ok = getenv("SERL_AMD_MBV3_STREAM") == nullptr || strcmp(getenv("SERL_AMD_MBV3_STREAM"), "0") != 0;   // A/B switch
-  if (stream_ok && serl_get_matmul_precision() == 1 && K % 8 == 0 && K <= 80 && N <= 96 && act != ACT_HSIGMOID &&
+  if (stream_ok && serl_get_matmul_precision() == 1 && K % 8 == 0 && K <= 80 && N <= 96 && N % 4 == 0 && act != ACT_HSIGMOID &&
+      (((uintptr_t)b) & 15) == 0 &&
       (((uintptr_t)x | (uintptr_t)y) & 15) == 0) {
     const int ks = (K + 15) / 16, ntl = (N + 31) / 32;
 #define PW_CASE(KS_, NTL_) if (ks == KS_ && ntl == NTL_) return pw_stream_launch<KS_, NTL_>(x, w, b, y, M, K, N, act, accumulate, st);
