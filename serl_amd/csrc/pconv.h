@@ -82,6 +82,9 @@ typedef __attribute__((address_space(3))) void* pconv_lptr_t;
 
 template <int REC> __device__ __forceinline__ int pconv_swz(int j) { return REC == 128 ? ((j >> 1) & 7) : (j & 15); }
 
+// write-only dump area for lanes that must issue a store although their pixel does not exist (pconv_fwdw_kernel: the waits count stores)
+__device__ uint4 g_store_dump[192];
+
 // workgroup barrier that waits for this wave's LDS operations only: an LDS-DMA in flight (vmcnt) stays in flight
 __device__ __forceinline__ void pconv_lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -436,12 +439,12 @@ __global__ __launch_bounds__(G::NT, 1) void pconv_fwdw_kernel(const PConvFwdArgs
   for (int m = 0; m < MT; ++m) arow[m] = 2 * min(m * RPT + r / OWP, R - 1) * ROWB;
   const int rec0 = ox * REC, rec1 = (ox + 1) * REC;
   const int sw0 = pconv_swz<REC>(ox) << 4, sw1 = pconv_swz<REC>(ox + 1) << 4;
-  constexpr int LDC = F + 4;
-  constexpr int CH = G::CH, RPP = G::RPP;
-  const int n = (tid % CH) * 8;
-  float bs[8];
+  // The products are computed TRANSPOSED (weight fragment = the MFMA's A operand, pixel fragment = its B operand: the same
+  // registers, the same products over the same k, the same bits): a lane then holds, for its OWN pixel, output channels
+  // 32 wid + 8 g + 4 h .. + 3 in accumulator quad g -- the output leaves straight from the registers (below).
+  float4 bsq[4];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) bs[j] = a.bias[z][n + j];
+  for (int g = 0; g < 4; ++g) bsq[g] = *reinterpret_cast<const float4*>(a.bias[z] + wid * 32 + 8 * g + 4 * h);
   unsigned short* const out = a.y[z];
   unsigned char* const mk = a.rmask[z];
   // every ordinary load of the block is done before the item loop: inside it only the DMA and the stores are counted
@@ -496,11 +499,11 @@ __global__ __launch_bounds__(G::NT, 1) void pconv_fwdw_kernel(const PConvFwdArgs
       asm volatile("s_waitcnt lgkmcnt(" #CNT ")"                                                                        \
                    : "+v"(fh[(s) & 1][0]), "+v"(fl[(s) & 1][0]), "+v"(fh[(s) & 1][1]), "+v"(fl[(s) & 1][1]) : : "memory"); \
       _Pragma("unroll") for (int m = 0; m < MT; ++m)                                                                    \
-        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fl[(s) & 1][m]), rbh[s], acc[m], 0, 0, 0); \
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rbh[s], __builtin_bit_cast(bf16x8_t, fl[(s) & 1][m]), acc[m], 0, 0, 0); \
       _Pragma("unroll") for (int m = 0; m < MT; ++m)                                                                    \
-        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fh[(s) & 1][m]), rbl[s], acc[m], 0, 0, 0); \
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rbl[s], __builtin_bit_cast(bf16x8_t, fh[(s) & 1][m]), acc[m], 0, 0, 0); \
       _Pragma("unroll") for (int m = 0; m < MT; ++m)                                                                    \
-        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fh[(s) & 1][m]), rbh[s], acc[m], 0, 0, 0); \
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rbh[s], __builtin_bit_cast(bf16x8_t, fh[(s) & 1][m]), acc[m], 0, 0, 0); \
       /* the next item's DMA pieces behind the first NDMA / 2 k16 steps (early: the patch has the rest of the item to */ \
       /* land); branch-free (behind the last item the pieces copy zeros into the idle buffer) */                        \
       if (2 * (s) < NDMA) {                                                                                             \
@@ -517,54 +520,51 @@ __global__ __launch_bounds__(G::NT, 1) void pconv_fwdw_kernel(const PConvFwdArgs
 #undef PW_STEP
 #undef PW_LD
 #undef PW_IMM
-    pconv_lds_barrier();                   // every wave is done with the patch before the output tile overwrites it
-
-    // ---- S-format output through an fp32 tile in LDS (as sgemm.h): 8 consecutive channels of one pixel per thread
-    float* const Cs = reinterpret_cast<float*>(patch);
+    // ---- S-format output straight from the accumulators (no LDS tile, no barrier).  Per pixel row a lane pair (r, h = 0 / 1)
+    // holds channel quads 8 g + 4 h .. + 3; after bias / ReLU / hi-lo split one v_permlane32_swap per dword and quad pair
+    // (vdst = quad k, src = quad k + 1: lanes 32-63 of vdst swap with lanes 0-31 of src) leaves 8 consecutive channels in
+    // every lane -- 16-byte stores of the hi and of the lo plane, and the mask byte of those 8 channels.  Every lane issues
+    // every store (the wait at the top of the next item is a COUNT): lanes whose pixel does not exist (the padding column,
+    // rows past the image's last band) store to a dump area nobody reads.
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+    for (int m = 0; m < MT; ++m) {
+      const int row0 = m * 32 + r;
+      const int oyl = row0 / OWP, oxx = row0 & (OWP - 1);
+      const bool valid = oyl < rows_here && oxx < a.OW;
+      const size_t pix = (size_t)(b * a.OH + oy0 + (valid ? oyl : 0)) * a.OW + (valid ? oxx : 0);
+      uint32_t hq[4][2], lq[4][2];
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int row = m * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-        Cs[row * LDC + wid * 32 + r] = acc[m][q];
+      for (int g = 0; g < 4; ++g) {
+        float v0 = fmaf(acc[m][4 * g], 1.0f, bsq[g].x), v1 = fmaf(acc[m][4 * g + 1], 1.0f, bsq[g].y);
+        float v2 = fmaf(acc[m][4 * g + 2], 1.0f, bsq[g].z), v3 = fmaf(acc[m][4 * g + 3], 1.0f, bsq[g].w);
+        if (a.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+        split_pair(v0, v1, hq[g][0], lq[g][0]);
+        split_pair(v2, v3, hq[g][1], lq[g][1]);
       }
-    pconv_lds_barrier();
-    // every thread runs every pass and issues the same number of stores (rows past the band's end and the padding
-    // column are redirected to the last valid row / column), so that the wait at the top of the next item is a COUNT
-    const uint32_t cs_base = (uint32_t)(size_t)(pconv_lptr_t)Cs;
 #pragma unroll
-    for (int pass = 0; pass < G::PASSES; ++pass) {
-      const int row0 = tid / CH + pass * RPP;
-      const int oyl = min(row0 / OWP, rows_here - 1), oxx = min(row0 & (OWP - 1), a.OW - 1);
-      const int row = oyl * OWP + oxx;
-      const size_t pix = (size_t)(b * a.OH + oy0 + oyl) * a.OW + oxx;
-      u32x4_t c0, c1;      // LDS reads by hand (pconv_fwd_kernel): no compiler-inserted vmcnt(0) behind the DMA
-      asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
-                   : "=&v"(c0), "=&v"(c1) : "v"(cs_base + (uint32_t)(row * LDC + n) * 4u) : "memory");
-      float v[8] = {__uint_as_float(c0[0]), __uint_as_float(c0[1]), __uint_as_float(c0[2]), __uint_as_float(c0[3]),
-                    __uint_as_float(c1[0]), __uint_as_float(c1[1]), __uint_as_float(c1[2]), __uint_as_float(c1[3])};
+      for (int k = 0; k < 4; k += 2) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        v[j] = fmaf(v[j], 1.0f, bs[j]);
-        if (a.relu) v[j] = fmaxf(v[j], 0.f);
-      }
-      u32x4_t hi, lo;
-      uint32_t hh, ll;
-      split_pair(v[0], v[1], hh, ll); hi[0] = hh; lo[0] = ll;
-      split_pair(v[2], v[3], hh, ll); hi[1] = hh; lo[1] = ll;
-      split_pair(v[4], v[5], hh, ll); hi[2] = hh; lo[2] = ll;
-      split_pair(v[6], v[7], hh, ll); hi[3] = hh; lo[3] = ll;
-      unsigned short* dst = out + pix * 2 * F + n;
-      *reinterpret_cast<u32x4_t*>(dst) = hi;
-      *reinterpret_cast<u32x4_t*>(dst + F) = lo;
-      if (mk != nullptr) {
-        uint32_t bits = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          bits |= (hi[j] & 0x7fffu) ? (1u << (2 * j)) : 0u;
-          bits |= (hi[j] & 0x7fff0000u) ? (2u << (2 * j)) : 0u;
+        for (int e = 0; e < 2; ++e) {
+          auto sh = __builtin_amdgcn_permlane32_swap(hq[k][e], hq[k + 1][e], false, false);
+          hq[k][e] = sh[0]; hq[k + 1][e] = sh[1];
+          auto sl = __builtin_amdgcn_permlane32_swap(lq[k][e], lq[k + 1][e], false, false);
+          lq[k][e] = sl[0]; lq[k + 1][e] = sl[1];
         }
-        mk[pix * (F >> 3) + (n >> 3)] = (unsigned char)bits;
+        const u32x4_t hi = {hq[k][0], hq[k][1], hq[k + 1][0], hq[k + 1][1]}, lo = {lq[k][0], lq[k][1], lq[k + 1][0], lq[k + 1][1]};
+        const int chan = wid * 32 + 8 * k + 8 * h;          // lanes 0-31: channels of quads k (both halves); lanes 32-63: of quad k + 1
+        unsigned short* dst = valid ? out + pix * 2 * F + chan : reinterpret_cast<unsigned short*>(g_store_dump) + lane * 8;
+        *reinterpret_cast<u32x4_t*>(dst) = hi;
+        *reinterpret_cast<u32x4_t*>(dst + (valid ? F : 512)) = lo;
+        if (mk != nullptr) {
+          uint32_t bits = 0;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            bits |= (hi[j] & 0x7fffu) ? (1u << (2 * j)) : 0u;
+            bits |= (hi[j] & 0x7fff0000u) ? (2u << (2 * j)) : 0u;
+          }
+          unsigned char* md = valid ? mk + pix * (F >> 3) + (chan >> 3) : reinterpret_cast<unsigned char*>(g_store_dump) + 2048 + lane;
+          *md = (unsigned char)bits;
+        }
       }
     }
   }
